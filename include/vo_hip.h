@@ -1,0 +1,158 @@
+/*
+ * vo_hip.h -- C ABI of libvo_hip.so, the MI355X (gfx950) implementation of the
+ * data-parallel front end of Heusini/visual_odometry.
+ *
+ * The reference has no FFI of its own: its hot path is three Python calls into OpenCV
+ * 4.6.0.  Each entry point below names the reference call site it stands in for
+ * (paths relative to the reference repository) and the OpenCV routine behind it.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless its name ends in
+ *     `_host`; the library never allocates or frees caller-visible memory;
+ *   - every device entry point takes a hipStream_t (passed as void*), enqueues work on it
+ *     and returns without synchronising; host-only helpers (vo_host_*) touch no GPU state;
+ *   - return value: 0 = VO_OK, negative = VO_E* below; vo_last_error() gives the text;
+ *   - scratch memory comes in through an explicit workspace argument whose size the
+ *     matching *_workspace_bytes() call reports;
+ *   - thread-safe for distinct streams; the only global state is the per-thread
+ *     last-error string.
+ */
+#ifndef VO_HIP_H
+#define VO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VO_OK            0
+#define VO_EINVAL       -1   /* bad argument (null pointer, negative size, ...)      */
+#define VO_ESIZE        -2   /* size outside what the kernels support                */
+#define VO_EWORKSPACE   -3   /* workspace too small                                  */
+#define VO_EHIP         -4   /* a HIP runtime call failed                            */
+#define VO_ENODEVICE    -5   /* no gfx950 device / kernels cannot load               */
+
+#define VO_DESC_DIM     128  /* SIFT descriptor length (reference src/features.py:33-41) */
+#define VO_KNN_MAX_TRAIN 262144 /* BFMatcher's own limit on train rows  */
+
+/* bits of the flag word written by vo_desc_f32_to_i8 */
+#define VO_DESC_BAD_VALUE  1   /* an element is not an integer in [0,255]            */
+#define VO_DESC_BAD_NORM   2   /* a row has ||desc||_2 > 1024: integer keys could mis-order
+                                  where OpenCV's f32 sqrt collides      */
+
+const char* vo_last_error(void);
+int  vo_version(void);
+/* 0 when a gfx950 device is visible and the code object loads, VO_ENODEVICE otherwise */
+int  vo_device_check(int device);
+
+/* ------------------------------------------------------------------------------------
+ * Descriptor matching.  Replaces cv.BFMatcher().knnMatch(des_i, des_j, k=2) at reference
+ * src/features.py:100-101 (OpenCV features2d BFMatcher::knnMatchImpl -> core batchDistance).
+ * ---------------------------------------------------------------------------------- */
+
+/* f32 descriptors holding integers 0..255 (what cv.SIFT produces) -> int8 (value-128) and
+ * the squared norms of the int8 rows.  flags (1 x int32, caller zeroes) receives VO_DESC_BAD_*. */
+int vo_desc_f32_to_i8(const float* desc, int n, int8_t* out_i8, int32_t* out_norm,
+                      int32_t* flags, void* stream);
+
+size_t vo_knn2_workspace_bytes(int nq, int nt, int batch);
+
+/* For each of `batch` independent (query set, train set) pairs, all of the same shape:
+ *   q      batch x nq x 128 int8     qnorm  batch x nq int32
+ *   t      batch x nt x 128 int8     tnorm  batch x nt int32
+ *   idx    batch x nq x 2 int32      train indices of the nearest and second nearest row,
+ *                                    ties to the lower index; -1 where nt < 2 leaves a gap
+ *   d2     batch x nq x 2 int32      exact squared L2 distances (INT32_MAX where idx = -1)
+ * int8 MFMA, int32 accumulation: D = |q|^2 + |t|^2 - 2 q.t exactly. */
+int vo_knn2_l2_i8(const int8_t* q, const int32_t* qnorm, int nq,
+                  const int8_t* t, const int32_t* tnorm, int nt,
+                  int32_t* idx, int32_t* d2, int batch,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* Lowe ratio test of reference src/features.py:103-106 on device:
+ *   keep[i] = (double)sqrtf(d2[i][0]) < ratio * (double)sqrtf(d2[i][1])   (strict)
+ * keep: n x uint8.  count (1 x int32, caller zeroes) receives the number kept. */
+int vo_ratio_test(const int32_t* d2, int n, double ratio, uint8_t* keep, int32_t* count,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * RANSAC hypothesis scoring.  Replaces the computeError + findInliers pair that
+ * RANSACPointSetRegistrator::run executes once per model (OpenCV calib3d ptsetreg.cpp),
+ * i.e. the inside of
+ *   cv2.findFundamentalMat(..., cv2.RANSAC, ...)   reference src/utils/geometry.py:39
+ *   cv2.findEssentialMat(..., cv2.RANSAC, ...)     reference src/utils/geometry.py:44
+ *   cv.solvePnPRansac(..., SOLVEPNP_P3P, ...)      reference src/pnp.py:16-26
+ * thr2 is (float)(threshold*threshold); a point is an inlier iff (float)err <= thr2.
+ * counts[h] = number of inliers of model h, or -1 when valid[h] == 0 (valid may be NULL).
+ * ---------------------------------------------------------------------------------- */
+
+/* models H x 9 f64 (row-major F), pts N x 4 f32 (x1 y1 x2 y2).  Symmetric squared
+ * point-to-epipolar-line distance (FMEstimatorCallback::computeError, fundam.cpp). */
+int vo_score_fund(const double* models, const uint8_t* valid, int H,
+                  const float* pts, int N, float thr2, int32_t* counts, void* stream);
+/* models H x 9 f64 (row-major E), pts N x 4 f64 (K-normalised x1 y1 x2 y2).  Sampson
+ * error (EMEstimatorCallback::computeError, five-point.cpp). */
+int vo_score_ess(const double* models, const uint8_t* valid, int H,
+                 const double* pts, int N, float thr2, int32_t* counts, void* stream);
+/* models H x 12 f64 (R row-major, then t), K4_host = {fx, fy, cx, cy} on the HOST,
+ * obj N x 3 f32, img N x 2 f32.  Squared reprojection error, f64 projection rounded to f32
+ * (PnPRansacCallback::computeError, solvepnp.cpp -> projectPoints, calibration.cpp). */
+int vo_score_pnp(const double* models, const uint8_t* valid, int H,
+                 const float* obj, const float* img, const double* K4_host, int N,
+                 float thr2, int32_t* counts, void* stream);
+
+/* Inlier mask (N x uint8) of ONE model (device pointer to 9 / 9 / 12 f64). */
+int vo_mask_fund(const double* model, const float* pts, int N, float thr2, uint8_t* mask, void* stream);
+int vo_mask_ess(const double* model, const double* pts, int N, float thr2, uint8_t* mask, void* stream);
+int vo_mask_pnp(const double* model, const float* obj, const float* img, const double* K4_host,
+                int N, float thr2, uint8_t* mask, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Minimal solvers, one hypothesis per sample.  Replace the runKernel callbacks of the same
+ * three OpenCV calls: run7Point (fundam.cpp), the five-point solver (five-point.cpp),
+ * p3p::solve + ranking by reprojection error (p3p.cpp, solvepnp.cpp).
+ * samples: H x m int32 indices into the correspondence arrays (m = 7, 5, 4).
+ * ---------------------------------------------------------------------------------- */
+
+/* models H x 3 x 9 f64, nmodels H int32 (0..3). */
+int vo_solve_7pt(const int32_t* samples, int H, const float* pts, int N,
+                 double* models, int32_t* nmodels, void* stream);
+/* models H x 10 x 9 f64, nmodels H int32 (0..10).  pts N x 4 f64 K-normalised. */
+int vo_solve_5pt(const int32_t* samples, int H, const double* pts, int N,
+                 double* models, int32_t* nmodels, void* stream);
+/* models H x 12 f64 (R after the Rodrigues round trip OpenCV's model format implies, t),
+ * rvecs H x 3 f64, nmodels H int32 (0 or 1). */
+int vo_solve_p3p(const int32_t* samples, int H, const float* obj, const float* img,
+                 const double* K4_host, int N, double* models, double* rvecs,
+                 int32_t* nmodels, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Best-model bookkeeping of RANSACPointSetRegistrator::run (ptsetreg.cpp): strict
+ * "good > max(maxGood, modelPoints-1)" in iteration-then-model order, with the adaptive
+ * iteration count of RANSACUpdateNumIters cutting the scan short.
+ * counts: n_iters x max_models int32, nmodels: n_iters int32 (NULL = 1 each, or counts<0
+ * marks a missing model).  result (4 x int32): best_iter (-1 none), best_model, max_good,
+ * final niters.
+ * ---------------------------------------------------------------------------------- */
+int vo_ransac_replay(const int32_t* counts, const int32_t* nmodels, int n_iters, int max_models,
+                     int n_points, int model_points, double confidence, int max_iters,
+                     int32_t* result, void* stream);
+/* result (2 x int32): largest count and the lowest index holding it (pure argmax mode). */
+int vo_argmax_first(const int32_t* counts, int n, int32_t* result, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Host-only helpers (no GPU): the sample stream of RANSACPointSetRegistrator::getSubset
+ * driven by cv::RNG((uint64)-1), incl. FMEstimatorCallback::checkSubset when pts4_host
+ * (N x 4 f32: x1 y1 x2 y2) is given.  Returns the number of iterations generated (the
+ * stream stops at the first iteration whose 10000 attempts all fail), or a VO_E* code.
+ * ---------------------------------------------------------------------------------- */
+int vo_host_gen_subsets(int n_points, int model_points, int max_iters,
+                        const float* pts4_host, int32_t* subsets_host);
+int vo_host_update_num_iters(double p, double ep, int model_points, int max_iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

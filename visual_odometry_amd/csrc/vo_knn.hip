@@ -1,0 +1,395 @@
+// vo_knn.hip -- brute-force 2-nearest-neighbour search over 128-D SIFT descriptors on
+// gfx950 int8 MFMA.  Stands in for cv.BFMatcher().knnMatch(des_i, des_j, k=2) at reference
+// src/features.py:100-101 (semantics: SURVEY.md Appendix A.1).
+//
+// Arithmetic: descriptors are integers 0..255 stored as int8 (value - 128).  For one query
+// the order of squared distances D = |q|^2 + |t|^2 - 2 q.t over train rows is the reverse
+// order of key = 2 q.t - |t|^2, so each lane maximises key; q.t comes out of
+// v_mfma_i32_32x32x32_i8 exactly (int32 accumulate), and D is rebuilt at the very end.
+//
+// Data movement: a workgroup (4 waves) owns 256 query rows and one split of the train rows.
+// Every wave keeps its 64 query rows as MFMA B fragments in registers for the whole sweep
+// (queries sit on the MFMA column = lane axis, so a lane's running top-2 never leaves the
+// lane).  Train rows stream through LDS in 128-row chunks (double buffered, 16-byte slots
+// XOR-swizzled so the ds_read_b128 of an A fragment is bank-conflict free) and are shared
+// by the four waves.  Per 32x32 output tile the VALU does 3 ops per element:
+//     p  = (dot << 9) + c[row]        c[row] = (-|t|^2 << 8) | (15-tile)<<4 | (15-slot)
+//     m2 = med3(m1, m2, p) ; m1 = max(m1, p)
+// The low 8 bits make p unique inside a 16-tile segment and order equal keys by ascending
+// train index, which is OpenCV's tie rule (strict '<' insertion while scanning upwards).
+#include "vo_common.h"
+#include <limits.h>
+
+namespace {
+
+constexpr int kDim = VO_DESC_DIM;
+constexpr int kTileRows = 32;
+constexpr int kChunkTiles = 4;
+constexpr int kChunkRows = kTileRows * kChunkTiles;          // 128 train rows per LDS stage
+constexpr int kSegTiles = 16;                                 // tile index bits in the key
+constexpr int kWaveQ = 64;                                    // query rows per wave
+constexpr int kWgWaves = 4;
+constexpr int kWgQ = kWaveQ * kWgWaves;                       // 256 query rows per workgroup
+constexpr int kWgThreads = 64 * kWgWaves;
+constexpr int kBufBytes = kChunkRows * kDim + kChunkRows * 4; // rows + their c[] words
+constexpr int kLdsBytes = 2 * kBufBytes;
+
+struct Top2 {
+    int k1, j1, k2, j2;   // keys descending; j = -1 marks an empty slot (key INT_MIN)
+};
+
+__device__ __forceinline__ bool better(int ka, int ja, int kb, int jb)
+{
+    return ka > kb || (ka == kb && (unsigned)ja < (unsigned)jb);   // j=-1 -> 0xffffffff loses
+}
+
+// candidate arrives in ascending-j order relative to what is already held
+__device__ __forceinline__ void insert_later(Top2& r, int k, int j)
+{
+    if (j < 0) return;
+    if (k > r.k1) { r.k2 = r.k1; r.j2 = r.j1; r.k1 = k; r.j1 = j; }
+    else if (k > r.k2) { r.k2 = k; r.j2 = j; }
+}
+
+__device__ __forceinline__ Top2 merge2(const Top2& a, const Top2& b)
+{
+    Top2 o;
+    if (better(a.k1, a.j1, b.k1, b.j1)) {
+        o.k1 = a.k1; o.j1 = a.j1;
+        if (better(a.k2, a.j2, b.k1, b.j1)) { o.k2 = a.k2; o.j2 = a.j2; }
+        else { o.k2 = b.k1; o.j2 = b.j1; }
+    } else {
+        o.k1 = b.k1; o.j1 = b.j1;
+        if (better(a.k1, a.j1, b.k2, b.j2)) { o.k2 = a.k1; o.j2 = a.j1; }
+        else { o.k2 = b.k2; o.j2 = b.j2; }
+    }
+    return o;
+}
+
+// v_med3_i32 has no clang builtin; one VALU op, inputs/outputs are ordinary VGPRs
+__device__ __forceinline__ int med3i(int a, int b, int c)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+__global__ __launch_bounds__(kWgThreads, 2)
+void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict__ t,
+                         const int32_t* __restrict__ tnorm, int nq, int nt,
+                         int rows_per_split, int nsplit, int4* __restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qblock = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+    q += (size_t)b * nq * kDim;
+    t += (size_t)b * nt * kDim;
+    tnorm += (size_t)b * nt;
+
+    const int row0 = split * rows_per_split;
+    const int row_end = min(nt, row0 + rows_per_split);
+    const int nchunks = row_end > row0 ? (row_end - row0 + kChunkRows - 1) / kChunkRows : 0;
+
+    // ---- query rows -> MFMA B fragments (lane: column = query lane&31, k-slice by lane>>5)
+    const int qrow = lane & 31, h = lane >> 5;
+    const int qbase = qblock * kWgQ + wave * kWaveQ;
+    v4i qb[2][4];
+#pragma unroll
+    for (int set = 0; set < 2; ++set) {
+        const int qi = qbase + set * 32 + qrow;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // unconditional load of a clamped row, then select: no branch around the load
+            const v4i v = *(const v4i*)(q + (size_t)min(qi, nq - 1) * kDim + 32 * s + 16 * h);
+            const v4i z = {0, 0, 0, 0};
+            qb[set][s] = qi < nq ? v : z;
+        }
+    }
+
+    // ---- staging registers (global -> regs early, regs -> LDS after the compute phase)
+    v4i st[4];
+    int stc = INT_MIN;
+    auto stage_load = [&](int chunk) {
+        const int rbase = row0 + chunk * kChunkRows;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + kWgThreads * i, r = idx >> 3, ck = idx & 7, gr = rbase + r;
+            const v4i v = *(const v4i*)(t + (size_t)min(gr, row_end - 1) * kDim + ck * 16);
+            const v4i z = {0, 0, 0, 0};
+            st[i] = gr < row_end ? v : z;          // rows past the split must be all-zero
+        }
+        if (tid < kChunkRows) {
+            const int gr = rbase + tid;
+            const int tn = tnorm[min(gr, row_end - 1)];
+            const int tile16 = ((gr - row0) >> 5) & (kSegTiles - 1);
+            const int i = tid & 31, slot = (i & 3) | ((i >> 3) << 2);
+            stc = gr < row_end ? (-tn) * 256 + ((15 - tile16) << 4) + (15 - slot) : INT_MIN;
+        }
+    };
+    auto stage_store = [&](int buf) {
+        char* base = smem + buf * kBufBytes;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + kWgThreads * i, r = idx >> 3, ck = idx & 7;
+            *(v4i*)(base + r * kDim + ((ck ^ ((r >> 1) & 7)) << 4)) = st[i];
+        }
+        if (tid < kChunkRows) ((int*)(base + kChunkRows * kDim))[tid] = stc;
+    };
+
+    Top2 run[2];
+#pragma unroll
+    for (int set = 0; set < 2; ++set) { run[set].k1 = run[set].k2 = INT_MIN; run[set].j1 = run[set].j2 = -1; }
+    int m1[2][2], m2[2][2];          // [set][chain] packed running top-2 of the current segment
+#pragma unroll
+    for (int set = 0; set < 2; ++set)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) m1[set][c] = m2[set][c] = INT_MIN;
+
+    auto fold = [&](int seg_row_base) {
+#pragma unroll
+        for (int set = 0; set < 2; ++set) {
+            const int a1 = m1[set][0], a2 = m2[set][0], b1 = m1[set][1], b2 = m2[set][1];
+            const int n1 = max(a1, b1);
+            const int n2 = max3i(min(a1, b1), a2, b2);
+            const int pv[2] = {n1, n2};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int p = pv[e];
+                const int slot = 15 - (p & 15), tile16 = 15 - ((p >> 4) & 15);
+                const int i = (slot & 3) + ((slot >> 2) << 3) + 4 * h;
+                const int j = p == INT_MIN ? -1 : seg_row_base + tile16 * kTileRows + i;
+                insert_later(run[set], p >> 8, j);
+            }
+            m1[set][0] = m2[set][0] = m1[set][1] = m2[set][1] = INT_MIN;
+        }
+    };
+
+    if (nchunks > 0) {
+        stage_load(0);
+        stage_store(0);
+    }
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        if (chunk + 1 < nchunks) stage_load(chunk + 1);
+
+        const char* base = smem + buf * kBufBytes;
+        const int* cbase = (const int*)(base + kChunkRows * kDim);
+#pragma unroll
+        for (int tile = 0; tile < kChunkTiles; ++tile) {
+            const char* tb = base + tile * kTileRows * kDim;
+            v4i va[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                va[s] = *(const v4i*)(tb + qrow * kDim + (((2 * s + h) ^ ((qrow >> 1) & 7)) << 4));
+            v4i cv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                cv[g] = *(const v4i*)(cbase + tile * kTileRows + 8 * g + 4 * h);
+
+#pragma unroll
+            for (int set = 0; set < 2; ++set) {
+                v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(va[s], qb[set][s], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = (acc[r] << 9) + cv[r >> 2][r & 3];
+                    const int c = r & 1;
+                    m2[set][c] = med3i(m1[set][c], m2[set][c], p);
+                    m1[set][c] = max(m1[set][c], p);
+                }
+            }
+        }
+
+        if (chunk + 1 < nchunks) stage_store(buf ^ 1);
+        if (((chunk + 1) & (kSegTiles / kChunkTiles - 1)) == 0 || chunk + 1 == nchunks)
+            fold(row0 + (chunk / (kSegTiles / kChunkTiles)) * (kSegTiles * kTileRows));
+        __syncthreads();
+    }
+
+    // ---- the two lane halves hold the same query over interleaved train rows: merge
+#pragma unroll
+    for (int set = 0; set < 2; ++set) {
+        Top2 o;
+        o.k1 = __shfl_xor(run[set].k1, 32); o.j1 = __shfl_xor(run[set].j1, 32);
+        o.k2 = __shfl_xor(run[set].k2, 32); o.j2 = __shfl_xor(run[set].j2, 32);
+        const Top2 mrg = merge2(run[set], o);
+        const int qi = qbase + set * 32 + qrow;
+        if (h == 0 && qi < nq)
+            partial[((size_t)b * nsplit + split) * nq + qi] = make_int4(mrg.k1, mrg.j1, mrg.k2, mrg.j2);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void knn2_merge_kernel(const int4* __restrict__ partial, const int32_t* __restrict__ qnorm,
+                       int nq, int nsplit, int32_t* __restrict__ idx, int32_t* __restrict__ d2)
+{
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (qi >= nq) return;
+    Top2 r;
+    r.k1 = r.k2 = INT_MIN; r.j1 = r.j2 = -1;
+    for (int s = 0; s < nsplit; ++s) {
+        const int4 p = partial[((size_t)b * nsplit + s) * nq + qi];
+        insert_later(r, p.x, p.y);
+        insert_later(r, p.z, p.w);
+    }
+    const int qn = qnorm[(size_t)b * nq + qi];
+    const size_t o = ((size_t)b * nq + qi) * 2;
+    *(int2*)(idx + o) = make_int2(r.j1, r.j2);
+    *(int2*)(d2 + o) = make_int2(r.j1 >= 0 ? qn - r.k1 : INT_MAX, r.j2 >= 0 ? qn - r.k2 : INT_MAX);
+}
+
+// f32 (integers 0..255) -> int8 (value-128) + squared norm of the int8 row; 32 lanes per row
+__global__ __launch_bounds__(256)
+void desc_f32_to_i8_kernel(const float* __restrict__ desc, int n, int8_t* __restrict__ out,
+                           int32_t* __restrict__ norm, int32_t* __restrict__ flags)
+{
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    int bad = 0, s = 0, su = 0;
+    if (row < n) {
+        const float4 v = *(const float4*)(desc + (size_t)row * kDim + 4 * l);
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        char4 o;
+        signed char ov[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float x = f[k];
+            if (!(x >= 0.f && x <= 255.f) || x != truncf(x)) bad = VO_DESC_BAD_VALUE;
+            const int u = (int)fminf(fmaxf(x, 0.f), 255.f);
+            const int c = u - 128;
+            ov[k] = (signed char)c;
+            s += c * c;
+            su += u * u;
+        }
+        o.x = ov[0]; o.y = ov[1]; o.z = ov[2]; o.w = ov[3];
+        *(char4*)(out + (size_t)row * kDim + 4 * l) = o;
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off);
+        su += __shfl_xor(su, off);
+    }
+    if (row < n && l == 0) {
+        norm[row] = s;
+        if (su > (1 << 20)) bad |= VO_DESC_BAD_NORM;
+    }
+    if (bad) atomicOr(flags, bad);
+}
+
+__global__ __launch_bounds__(256)
+void ratio_test_kernel(const int32_t* __restrict__ d2, int n, double ratio,
+                       uint8_t* __restrict__ keep, int32_t* __restrict__ count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int k = 0;
+    if (i < n) {
+        const int2 d = *(const int2*)(d2 + 2 * (size_t)i);
+        if (d.x != INT_MAX && d.y != INT_MAX) {
+            const float m = __fsqrt_rn((float)d.x), s = __fsqrt_rn((float)d.y);
+            k = (double)m < ratio * (double)s;
+        }
+        keep[i] = (uint8_t)k;
+    }
+    const unsigned long long bal = __ballot(k);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(count, __popcll(bal));
+}
+
+struct KnnPlan { int nsplit, rows_per_split, nqb; };
+
+int cu_count()
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus = v;
+        else
+            cus = 256;
+    }
+    return cus;
+}
+
+KnnPlan knn_plan(int nq, int nt, int batch)
+{
+    KnnPlan p;
+    p.nqb = vo_ceil_div(nq > 0 ? nq : 1, kWgQ);
+    const long want = 2L * cu_count();                       // two workgroups per CU
+    long ns = (want + (long)p.nqb * batch - 1) / ((long)p.nqb * batch);
+    const int max_ns = vo_ceil_div(nt > 0 ? nt : 1, kSegTiles * kTileRows);
+    if (ns > max_ns) ns = max_ns;
+    if (ns < 1) ns = 1;
+    int rps = vo_ceil_div(nt > 0 ? nt : 1, (int)ns);
+    rps = vo_ceil_div(rps, kChunkRows) * kChunkRows;
+    p.rows_per_split = rps;
+    p.nsplit = vo_ceil_div(nt > 0 ? nt : 1, rps);
+    return p;
+}
+
+}  // namespace
+
+extern "C" size_t vo_knn2_workspace_bytes(int nq, int nt, int batch)
+{
+    if (nq <= 0 || nt <= 0 || batch <= 0) return 16;
+    const KnnPlan p = knn_plan(nq, nt, batch);
+    return (size_t)batch * p.nsplit * nq * sizeof(int4);
+}
+
+extern "C" int vo_knn2_l2_i8(const int8_t* q, const int32_t* qnorm, int nq,
+                             const int8_t* t, const int32_t* tnorm, int nt,
+                             int32_t* idx, int32_t* d2, int batch,
+                             void* workspace, size_t workspace_bytes, void* stream)
+{
+    VO_CHECK_ARG(nq >= 0 && nt >= 0 && batch >= 0, VO_EINVAL, "vo_knn2_l2_i8: negative size");
+    if (nq == 0 || batch == 0) return VO_OK;
+    VO_CHECK_ARG(q && qnorm && idx && d2, VO_EINVAL, "vo_knn2_l2_i8: null query/output pointer");
+    VO_CHECK_ARG(nt <= VO_KNN_MAX_TRAIN, VO_ESIZE, "vo_knn2_l2_i8: nt=%d exceeds %d train rows", nt, VO_KNN_MAX_TRAIN);
+    VO_CHECK_ARG(nt == 0 || (t && tnorm), VO_EINVAL, "vo_knn2_l2_i8: null train pointer");
+    VO_CHECK_ARG(batch <= 65535, VO_ESIZE, "vo_knn2_l2_i8: batch=%d exceeds 65535", batch);
+    VO_CHECK_ARG((((uintptr_t)q | (uintptr_t)t) & 15) == 0 && (((uintptr_t)idx | (uintptr_t)d2) & 7) == 0,
+                 VO_EINVAL, "vo_knn2_l2_i8: descriptors must be 16-byte aligned, outputs 8-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const KnnPlan p = knn_plan(nq, nt, batch);
+    const size_t need = vo_knn2_workspace_bytes(nq, nt, batch);
+    VO_CHECK_ARG(workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0, VO_EWORKSPACE,
+                 "vo_knn2_l2_i8: workspace of %zu bytes (16-byte aligned) required, got %zu", need, workspace_bytes);
+    VO_CHECK_ARG(p.nsplit <= 65535, VO_ESIZE, "vo_knn2_l2_i8: too many train splits");
+    int4* partial = (int4*)workspace;
+    dim3 grid(p.nqb, p.nsplit, batch);
+    hipLaunchKernelGGL(knn2_partial_kernel, grid, dim3(kWgThreads), kLdsBytes, s, q, t, tnorm, nq, nt,
+                       p.rows_per_split, p.nsplit, partial);
+    VO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(knn2_merge_kernel, dim3(vo_ceil_div(nq, 256), batch), dim3(256), 0, s, partial, qnorm,
+                       nq, p.nsplit, idx, d2);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}
+
+extern "C" int vo_desc_f32_to_i8(const float* desc, int n, int8_t* out_i8, int32_t* out_norm,
+                                 int32_t* flags, void* stream)
+{
+    VO_CHECK_ARG(n >= 0, VO_EINVAL, "vo_desc_f32_to_i8: negative row count");
+    if (n == 0) return VO_OK;
+    VO_CHECK_ARG(desc && out_i8 && out_norm && flags, VO_EINVAL, "vo_desc_f32_to_i8: null pointer");
+    VO_CHECK_ARG(((uintptr_t)desc & 15) == 0 && ((uintptr_t)out_i8 & 3) == 0, VO_EINVAL,
+                 "vo_desc_f32_to_i8: desc must be 16-byte aligned");
+    hipLaunchKernelGGL(desc_f32_to_i8_kernel, dim3(vo_ceil_div(n, 8)), dim3(256), 0, (hipStream_t)stream,
+                       desc, n, out_i8, out_norm, flags);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}
+
+extern "C" int vo_ratio_test(const int32_t* d2, int n, double ratio, uint8_t* keep, int32_t* count, void* stream)
+{
+    VO_CHECK_ARG(n >= 0, VO_EINVAL, "vo_ratio_test: negative size");
+    if (n == 0) return VO_OK;
+    VO_CHECK_ARG(d2 && keep && count, VO_EINVAL, "vo_ratio_test: null pointer");
+    hipLaunchKernelGGL(ratio_test_kernel, dim3(vo_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       d2, n, ratio, keep, count);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}

@@ -1,0 +1,260 @@
+"""Device-level operators: torch tensors on an MI355X in, torch tensors out, no host sync.
+
+Thin, typed wrappers over the C ABI of ``libvo_hip.so`` (``include/vo_hip.h``).  torch is used for
+device memory and the current HIP stream only; all arithmetic happens in the library's kernels.
+Every function launches on ``torch.cuda.current_stream()`` and returns immediately.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_INT_MAX = 2**31 - 1
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _dev(t: torch.Tensor, dtype: torch.dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.VoError(f"{name} must live on the GPU")
+    if t.dtype != dtype:
+        raise _lib.VoError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _K4(K) -> "C.Array":
+    K = np.asarray(K, dtype=np.float64)
+    if K.shape == (3, 3):
+        vals = (K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+    else:
+        vals = tuple(K.reshape(4))
+    return (C.c_double * 4)(*vals)
+
+
+def thr2_of(threshold: float) -> float:
+    """findInliers' ``(float)(threshold*threshold)`` (f64 product rounded once to f32)."""
+    return float(np.float32(float(threshold) * float(threshold)))
+
+
+# ------------------------------------------------------------------------------- matching
+def desc_to_i8(desc: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(n,128) f32 integer-valued descriptors -> (int8 rows, int32 squared norms, int32 flag word)."""
+    _lib.require_device()
+    desc = _dev(desc, torch.float32, "desc")
+    if desc.ndim != 2 or desc.shape[1] != 128:
+        raise _lib.VoError(f"descriptors must be (n,128), got {tuple(desc.shape)}")
+    n = desc.shape[0]
+    out = torch.empty((n, 128), dtype=torch.int8, device=desc.device)
+    norm = torch.empty((n,), dtype=torch.int32, device=desc.device)
+    flags = torch.zeros((1,), dtype=torch.int32, device=desc.device)
+    _lib.check(_lib.load().vo_desc_f32_to_i8(_ptr(desc), n, _ptr(out), _ptr(norm), _ptr(flags), _stream()),
+               "vo_desc_f32_to_i8")
+    return out, norm, flags
+
+
+def knn2(q: torch.Tensor, qnorm: torch.Tensor, t: torch.Tensor, tnorm: torch.Tensor,
+         workspace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """q (B,nq,128)|(nq,128) int8, t likewise -> idx (...,nq,2) i32, d2 (...,nq,2) i32 (exact)."""
+    _lib.require_device()
+    lib = _lib.load()
+    q = _dev(q, torch.int8, "q"); t = _dev(t, torch.int8, "t")
+    qnorm = _dev(qnorm, torch.int32, "qnorm"); tnorm = _dev(tnorm, torch.int32, "tnorm")
+    batched = q.ndim == 3
+    q3 = q if batched else q[None]
+    t3 = t if batched else t[None]
+    B, nq, nt = q3.shape[0], q3.shape[1], t3.shape[1]
+    if t3.shape[0] != B or q3.shape[2] != 128 or t3.shape[2] != 128:
+        raise _lib.VoError("knn2: shape mismatch")
+    idx = torch.empty((B, nq, 2), dtype=torch.int32, device=q.device)
+    d2 = torch.empty((B, nq, 2), dtype=torch.int32, device=q.device)
+    need = lib.vo_knn2_workspace_bytes(nq, nt, B)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(((need + 15) // 16 * 16,), dtype=torch.uint8, device=q.device)
+    _lib.check(lib.vo_knn2_l2_i8(_ptr(q3), _ptr(qnorm), nq, _ptr(t3), _ptr(tnorm), nt, _ptr(idx), _ptr(d2), B,
+                                 _ptr(workspace), workspace.numel() * workspace.element_size(), _stream()),
+               "vo_knn2_l2_i8")
+    return (idx, d2) if batched else (idx[0], d2[0])
+
+
+def ratio_test(d2: torch.Tensor, ratio: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """d2 (n,2) i32 -> keep (n,) u8, count (1,) i32."""
+    _lib.require_device()
+    d2 = _dev(d2, torch.int32, "d2")
+    n = d2.shape[0]
+    keep = torch.empty((n,), dtype=torch.uint8, device=d2.device)
+    count = torch.zeros((1,), dtype=torch.int32, device=d2.device)
+    _lib.check(_lib.load().vo_ratio_test(_ptr(d2), n, float(ratio), _ptr(keep), _ptr(count), _stream()),
+               "vo_ratio_test")
+    return keep, count
+
+
+# ------------------------------------------------------------------------------- scoring
+def _valid(valid, H):
+    if valid is None:
+        return None
+    v = _dev(valid, torch.uint8, "valid")
+    if v.numel() != H:
+        raise _lib.VoError("valid must have one byte per model")
+    return v
+
+
+def score_fund(models: torch.Tensor, pts4: torch.Tensor, threshold: float,
+               valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _lib.require_device()
+    models = _dev(models, torch.float64, "models").reshape(-1, 9)
+    pts4 = _dev(pts4, torch.float32, "pts4").reshape(-1, 4)
+    H, N = models.shape[0], pts4.shape[0]
+    counts = torch.empty((H,), dtype=torch.int32, device=models.device)
+    _lib.check(_lib.load().vo_score_fund(_ptr(models), _ptr(_valid(valid, H)), H, _ptr(pts4), N,
+                                         thr2_of(threshold), _ptr(counts), _stream()), "vo_score_fund")
+    return counts
+
+
+def score_ess(models: torch.Tensor, pts4: torch.Tensor, threshold: float,
+              valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _lib.require_device()
+    models = _dev(models, torch.float64, "models").reshape(-1, 9)
+    pts4 = _dev(pts4, torch.float64, "pts4").reshape(-1, 4)
+    H, N = models.shape[0], pts4.shape[0]
+    counts = torch.empty((H,), dtype=torch.int32, device=models.device)
+    _lib.check(_lib.load().vo_score_ess(_ptr(models), _ptr(_valid(valid, H)), H, _ptr(pts4), N,
+                                        thr2_of(threshold), _ptr(counts), _stream()), "vo_score_ess")
+    return counts
+
+
+def score_pnp(models: torch.Tensor, obj: torch.Tensor, img: torch.Tensor, K, threshold: float,
+              valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _lib.require_device()
+    models = _dev(models, torch.float64, "models").reshape(-1, 12)
+    obj = _dev(obj, torch.float32, "obj").reshape(-1, 3)
+    img = _dev(img, torch.float32, "img").reshape(-1, 2)
+    H, N = models.shape[0], obj.shape[0]
+    if img.shape[0] != N:
+        raise _lib.VoError("score_pnp: obj/img length mismatch")
+    counts = torch.empty((H,), dtype=torch.int32, device=models.device)
+    _lib.check(_lib.load().vo_score_pnp(_ptr(models), _ptr(_valid(valid, H)), H, _ptr(obj), _ptr(img), _K4(K), N,
+                                        thr2_of(threshold), _ptr(counts), _stream()), "vo_score_pnp")
+    return counts
+
+
+def mask_fund(model: torch.Tensor, pts4: torch.Tensor, threshold: float) -> torch.Tensor:
+    _lib.require_device()
+    model = _dev(model, torch.float64, "model").reshape(9)
+    pts4 = _dev(pts4, torch.float32, "pts4").reshape(-1, 4)
+    mask = torch.empty((pts4.shape[0],), dtype=torch.uint8, device=pts4.device)
+    _lib.check(_lib.load().vo_mask_fund(_ptr(model), _ptr(pts4), pts4.shape[0], thr2_of(threshold), _ptr(mask),
+                                        _stream()), "vo_mask_fund")
+    return mask
+
+
+def mask_ess(model: torch.Tensor, pts4: torch.Tensor, threshold: float) -> torch.Tensor:
+    _lib.require_device()
+    model = _dev(model, torch.float64, "model").reshape(9)
+    pts4 = _dev(pts4, torch.float64, "pts4").reshape(-1, 4)
+    mask = torch.empty((pts4.shape[0],), dtype=torch.uint8, device=pts4.device)
+    _lib.check(_lib.load().vo_mask_ess(_ptr(model), _ptr(pts4), pts4.shape[0], thr2_of(threshold), _ptr(mask),
+                                       _stream()), "vo_mask_ess")
+    return mask
+
+
+def mask_pnp(model: torch.Tensor, obj: torch.Tensor, img: torch.Tensor, K, threshold: float) -> torch.Tensor:
+    _lib.require_device()
+    model = _dev(model, torch.float64, "model").reshape(12)
+    obj = _dev(obj, torch.float32, "obj").reshape(-1, 3)
+    img = _dev(img, torch.float32, "img").reshape(-1, 2)
+    mask = torch.empty((obj.shape[0],), dtype=torch.uint8, device=obj.device)
+    _lib.check(_lib.load().vo_mask_pnp(_ptr(model), _ptr(obj), _ptr(img), _K4(K), obj.shape[0],
+                                       thr2_of(threshold), _ptr(mask), _stream()), "vo_mask_pnp")
+    return mask
+
+
+# ------------------------------------------------------------------------------- solvers
+def solve_7pt(samples: torch.Tensor, pts4: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """samples (H,7) i32, pts4 (N,4) f32 -> models (H,3,9) f64, nmodels (H,) i32."""
+    _lib.require_device()
+    samples = _dev(samples, torch.int32, "samples").reshape(-1, 7)
+    pts4 = _dev(pts4, torch.float32, "pts4").reshape(-1, 4)
+    H = samples.shape[0]
+    models = torch.zeros((H, 3, 9), dtype=torch.float64, device=pts4.device)
+    nm = torch.zeros((H,), dtype=torch.int32, device=pts4.device)
+    _lib.check(_lib.load().vo_solve_7pt(_ptr(samples), H, _ptr(pts4), pts4.shape[0], _ptr(models), _ptr(nm),
+                                        _stream()), "vo_solve_7pt")
+    return models, nm
+
+
+def solve_5pt(samples: torch.Tensor, pts4: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """samples (H,5) i32, pts4 (N,4) f64 normalised -> models (H,10,9) f64, nmodels (H,) i32."""
+    _lib.require_device()
+    samples = _dev(samples, torch.int32, "samples").reshape(-1, 5)
+    pts4 = _dev(pts4, torch.float64, "pts4").reshape(-1, 4)
+    H = samples.shape[0]
+    models = torch.zeros((H, 10, 9), dtype=torch.float64, device=pts4.device)
+    nm = torch.zeros((H,), dtype=torch.int32, device=pts4.device)
+    _lib.check(_lib.load().vo_solve_5pt(_ptr(samples), H, _ptr(pts4), pts4.shape[0], _ptr(models), _ptr(nm),
+                                        _stream()), "vo_solve_5pt")
+    return models, nm
+
+
+def solve_p3p(samples: torch.Tensor, obj: torch.Tensor, img: torch.Tensor, K):
+    """samples (H,4) i32 -> models (H,12) f64 [R|t], rvecs (H,3) f64, nmodels (H,) i32."""
+    _lib.require_device()
+    samples = _dev(samples, torch.int32, "samples").reshape(-1, 4)
+    obj = _dev(obj, torch.float32, "obj").reshape(-1, 3)
+    img = _dev(img, torch.float32, "img").reshape(-1, 2)
+    H = samples.shape[0]
+    models = torch.zeros((H, 12), dtype=torch.float64, device=obj.device)
+    rvecs = torch.zeros((H, 3), dtype=torch.float64, device=obj.device)
+    nm = torch.zeros((H,), dtype=torch.int32, device=obj.device)
+    _lib.check(_lib.load().vo_solve_p3p(_ptr(samples), H, _ptr(obj), _ptr(img), _K4(K), obj.shape[0],
+                                        _ptr(models), _ptr(rvecs), _ptr(nm), _stream()), "vo_solve_p3p")
+    return models, rvecs, nm
+
+
+# ------------------------------------------------------------------------------- bookkeeping
+def ransac_replay(counts: torch.Tensor, nmodels: Optional[torch.Tensor], n_points: int, model_points: int,
+                  confidence: float, max_iters: int) -> torch.Tensor:
+    """counts (n_iters,max_models) i32 -> (4,) i32 [best_iter, best_model, max_good, niters]."""
+    _lib.require_device()
+    counts = _dev(counts, torch.int32, "counts")
+    if counts.ndim == 1:
+        counts = counts[:, None]
+    n_iters, max_models = counts.shape
+    nm = None if nmodels is None else _dev(nmodels, torch.int32, "nmodels")
+    result = torch.empty((4,), dtype=torch.int32, device=counts.device)
+    _lib.check(_lib.load().vo_ransac_replay(_ptr(counts), _ptr(nm), n_iters, max_models, n_points, model_points,
+                                            float(confidence), int(max_iters), _ptr(result), _stream()),
+               "vo_ransac_replay")
+    return result
+
+
+def argmax_first(counts: torch.Tensor) -> torch.Tensor:
+    _lib.require_device()
+    counts = _dev(counts, torch.int32, "counts").reshape(-1)
+    result = torch.empty((2,), dtype=torch.int32, device=counts.device)
+    _lib.check(_lib.load().vo_argmax_first(_ptr(counts), counts.numel(), _ptr(result), _stream()), "vo_argmax_first")
+    return result
+
+
+# ------------------------------------------------------------------------------- host helpers
+def gen_subsets(n_points: int, model_points: int, max_iters: int, pts4_host: Optional[np.ndarray] = None) -> np.ndarray:
+    """cv::RNG((uint64)-1) + getSubset sample stream (host only). (n_generated, model_points) i32."""
+    lib = _lib.load()
+    out = np.zeros((max(int(max_iters), 1), model_points), dtype=np.int32)
+    p = None
+    if pts4_host is not None:
+        pts4_host = np.ascontiguousarray(pts4_host, dtype=np.float32).reshape(-1, 4)
+        p = pts4_host.ctypes.data
+    n = lib.vo_host_gen_subsets(int(n_points), int(model_points), int(max_iters), p, out.ctypes.data)
+    _lib.check(n, "vo_host_gen_subsets")
+    return out[:n]

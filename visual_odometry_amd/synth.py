@@ -1,0 +1,87 @@
+"""Synthetic inputs of the shapes the reference feeds its hot path: there are no
+datasets and no SIFT detector in this environment, so benches and tests use these generators.
+
+* ``sift_like_pair``  -- descriptor sets with OpenCV-SIFT-like statistics (integer 0..255 values, L2
+  norm ~512) where a fraction of train rows are noisy copies of query rows;
+* ``two_view_scene`` / ``pnp_scene`` -- point correspondences for a camera with one of the
+  reference's hard-coded intrinsics (src/utils/dataloader.py:93-109), with pixel noise and outliers.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+
+K_KITTI = np.array([[718.856, 0, 607.1928], [0, 718.856, 185.2157], [0, 0, 1]], dtype=np.float64)
+K_MALAGA = np.array([[621.18428, 0, 404.0076], [0, 621.18428, 309.05989], [0, 0, 1]], dtype=np.float64)
+K_PARKING = np.array([[331.37, 0, 320], [0, 369.568, 240], [0, 0, 1]], dtype=np.float64)
+IMAGE_SIZE = {"kitti": (1241, 376), "malaga": (1024, 768), "parking": (640, 480)}
+
+
+def sift_like(n: int, rng: np.random.Generator) -> np.ndarray:
+    """(n,128) f32 rows: Gamma(0.6) magnitudes, L2-normalise, clip 0.2, renormalise, x512, round, saturate."""
+    d = rng.gamma(0.6, 1.0, size=(n, 128))
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-12)
+    d = np.minimum(d, 0.2)
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-12)
+    return np.clip(np.rint(d * 512.0), 0, 255).astype(np.float32)
+
+
+def sift_like_pair(nq: int, nt: int, seed: int = 1234, match_frac: float = 0.6,
+                   noise_sigma: float = 8.0) -> Tuple[np.ndarray, np.ndarray]:
+    """Query set and a train set in which ~match_frac of rows are noisy, shuffled copies of queries."""
+    rng = np.random.default_rng(seed)
+    q = sift_like(nq, rng)
+    t = sift_like(nt, rng)
+    m = min(nq, nt)
+    nmatch = int(match_frac * m)
+    src = rng.permutation(nq)[:nmatch]
+    dst = rng.permutation(nt)[:nmatch]
+    noisy = q[src] + rng.normal(0.0, noise_sigma, size=(nmatch, 128))
+    t[dst] = np.clip(np.rint(noisy), 0, 255).astype(np.float32)
+    return q, t
+
+
+def _rodrigues(axis_angle: np.ndarray) -> np.ndarray:
+    th = np.linalg.norm(axis_angle)
+    if th < 1e-15:
+        return np.eye(3)
+    k = axis_angle / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * (Kx @ Kx)
+
+
+def two_view_scene(n: int, K: np.ndarray = K_KITTI, size=(1241, 376), seed: int = 4321,
+                   noise_px: float = 0.3, outlier_frac: float = 0.3, max_rot_deg: float = 5.0):
+    """-> dict(R, t, X (n,3) f64 in cam1, p1 (n,2) f32, p2 (n,2) f32, inlier (n,) bool)."""
+    rng = np.random.default_rng(seed)
+    ax = rng.normal(size=3)
+    ax /= np.linalg.norm(ax)
+    R = _rodrigues(ax * np.deg2rad(max_rot_deg) * rng.uniform(0.3, 1.0))
+    t = rng.normal(size=3)
+    t /= np.linalg.norm(t)
+    w, h = size
+    z = rng.uniform(4.0, 40.0, n)
+    u = rng.uniform(0, w, n)
+    v = rng.uniform(0, h, n)
+    X = np.stack([(u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z], axis=1)
+    Xc = X @ R.T + t
+    p2 = Xc[:, :2] / Xc[:, 2:3] * np.array([K[0, 0], K[1, 1]]) + np.array([K[0, 2], K[1, 2]])
+    p1 = np.stack([u, v], axis=1)
+    if noise_px > 0:
+        p1 = p1 + rng.normal(0, noise_px, p1.shape)
+        p2 = p2 + rng.normal(0, noise_px, p2.shape)
+    inlier = np.ones(n, dtype=bool)
+    no = int(outlier_frac * n)
+    if no:
+        sel = rng.permutation(n)[:no]
+        p2[sel] = np.stack([rng.uniform(0, w, no), rng.uniform(0, h, no)], axis=1)
+        inlier[sel] = False
+    return dict(R=R, t=t, X=X, p1=p1.astype(np.float32), p2=p2.astype(np.float32), inlier=inlier, K=K)
+
+
+def pnp_scene(n: int, K: np.ndarray = K_MALAGA, size=(1024, 768), seed: int = 4321,
+              noise_px: float = 0.3, outlier_frac: float = 0.3, max_rot_deg: float = 5.0):
+    """-> dict(R, t (world->camera), obj (n,3) f32 world points, img (n,2) f32 pixels, inlier)."""
+    s = two_view_scene(n, K, size, seed, noise_px, outlier_frac, max_rot_deg)
+    return dict(R=s["R"], t=s["t"], obj=s["X"].astype(np.float32), img=s["p2"], inlier=s["inlier"], K=K)
