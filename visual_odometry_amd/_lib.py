@@ -73,7 +73,7 @@ def load() -> C.CDLL:
                 continue
             fn.restype = res
             fn.argtypes = args
-        if missing and not os.environ.get("VO_BRINGUP_ALLOW_MISSING"):
+        if missing:
             raise VoError(f"{LIB_PATH} lacks symbols declared in include/vo_hip.h: {missing}; rebuild it")
         _lib = lib
     return _lib
