@@ -152,6 +152,13 @@ int vo_host_gen_subsets(int n_points, int model_points, int max_iters,
                         const float* pts4_host, int32_t* subsets_host);
 int vo_host_update_num_iters(double p, double ep, int model_points, int max_iters);
 
+/* Host-only: the EPnP refit cv.solvePnPRansac(flags=SOLVEPNP_P3P) applies to the inliers of the
+ * winning model (reference src/pnp.py:16-26; OpenCV calib3d epnp.cpp).  obj_host n x 3 f64,
+ * img_host n x 2 f64 pixels, K4_host = {fx, fy, cx, cy}; R9_host row-major, t3_host: world ->
+ * camera.  Returns 1 on success, 0 when no finite pose comes out, or a VO_E* code. */
+int vo_host_epnp(const double* obj_host, const double* img_host, int n, const double* K4_host,
+                 double* R9_host, double* t3_host);
+
 #ifdef __cplusplus
 }
 #endif

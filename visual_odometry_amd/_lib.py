@@ -48,6 +48,7 @@ _SIGNATURES = {
     "vo_argmax_first": (_i, [_vp, _i, _vp, _vp]),
     "vo_host_gen_subsets": (_i, [_i, _i, _i, _vp, _vp]),
     "vo_host_update_num_iters": (_i, [_d, _d, _i, _i]),
+    "vo_host_epnp": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -78,7 +78,9 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 __global__ __launch_bounds__(kWgThreads, 2)
 void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict__ t,
                          const int32_t* __restrict__ tnorm, int nq, int nt,
-                         int rows_per_split, int nsplit, int4* __restrict__ partial)
+                         int rows_per_split, int nsplit, int4* __restrict__ partial,
+                         const int32_t* __restrict__ qnorm, int32_t* __restrict__ idx,
+                         int32_t* __restrict__ d2)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -219,8 +221,17 @@ void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict_
         o.k2 = __shfl_xor(run[set].k2, 32); o.j2 = __shfl_xor(run[set].j2, 32);
         const Top2 mrg = merge2(run[set], o);
         const int qi = qbase + set * 32 + qrow;
-        if (h == 0 && qi < nq)
-            partial[((size_t)b * nsplit + split) * nq + qi] = make_int4(mrg.k1, mrg.j1, mrg.k2, mrg.j2);
+        if (h == 0 && qi < nq) {
+            if (nsplit == 1) {
+                // one split sees every train row: finish here, no merge launch
+                const int qn = qnorm[(size_t)b * nq + qi];
+                const size_t o = ((size_t)b * nq + qi) * 2;
+                *(int2*)(idx + o) = make_int2(mrg.j1, mrg.j2);
+                *(int2*)(d2 + o) = make_int2(mrg.j1 >= 0 ? qn - mrg.k1 : INT_MAX, mrg.j2 >= 0 ? qn - mrg.k2 : INT_MAX);
+            } else {
+                partial[((size_t)b * nsplit + split) * nq + qi] = make_int4(mrg.k1, mrg.j1, mrg.k2, mrg.j2);
+            }
+        }
     }
 }
 
@@ -361,8 +372,9 @@ extern "C" int vo_knn2_l2_i8(const int8_t* q, const int32_t* qnorm, int nq,
     int4* partial = (int4*)workspace;
     dim3 grid(p.nqb, p.nsplit, batch);
     hipLaunchKernelGGL(knn2_partial_kernel, grid, dim3(kWgThreads), kLdsBytes, s, q, t, tnorm, nq, nt,
-                       p.rows_per_split, p.nsplit, partial);
+                       p.rows_per_split, p.nsplit, partial, qnorm, idx, d2);
     VO_LAUNCH_CHECK();
+    if (p.nsplit == 1) return VO_OK;
     hipLaunchKernelGGL(knn2_merge_kernel, dim3(vo_ceil_div(nq, 256), batch), dim3(256), 0, s, partial, qnorm,
                        nq, p.nsplit, idx, d2);
     VO_LAUNCH_CHECK();
