@@ -18,6 +18,7 @@ import torch
 
 from . import ops
 from .epnp import epnp_pose
+from .parallel import sharded_ransac
 from .rodrigues import rodrigues_matrix_to_vector
 
 _DBL_EPS = float(np.finfo(np.float64).eps)
@@ -42,9 +43,12 @@ def _h2d(a: np.ndarray) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------- fundamental
-def find_fundamental_ransac(points1, points2, threshold: float, confidence: float, max_iters: int
-                            ) -> Tuple[Optional[np.ndarray], Optional[np.ndarray], RansacInfo]:
-    """cv2.findFundamentalMat(p1, p2, cv2.RANSAC, threshold, confidence, max_iters)."""
+def find_fundamental_ransac(points1, points2, threshold: float, confidence: float, max_iters: int,
+                            group=None) -> Tuple[Optional[np.ndarray], Optional[np.ndarray], RansacInfo]:
+    """cv2.findFundamentalMat(p1, p2, cv2.RANSAC, threshold, confidence, max_iters).
+
+    group: None = this process alone.  ``parallel.WORLD`` or a ProcessGroup = the samples are split
+    over that group's ranks (every rank calls with the same inputs, all get the same result)."""
     m1 = np.ascontiguousarray(np.asarray(points1).reshape(-1, 2), dtype=np.float32)
     m2 = np.ascontiguousarray(np.asarray(points2).reshape(-1, 2), dtype=np.float32)
     if m1.shape[0] != m2.shape[0]:
@@ -76,23 +80,27 @@ def find_fundamental_ransac(points1, points2, threshold: float, confidence: floa
     if len(subsets) == 0:
         return None, mask0, info
     pts_d = _h2d(pts4)
-    models, nm = ops.solve_7pt(_h2d(subsets), pts_d)                     # (H,3,9), (H,)
-    H = models.shape[0]
-    valid = (torch.arange(3, device=nm.device, dtype=torch.int32)[None, :] < nm[:, None]).to(torch.uint8)
-    counts = ops.score_fund(models.reshape(H * 3, 9), pts_d, threshold, valid.reshape(-1))
-    res = ops.ransac_replay(counts.reshape(H, 3), nm, n, 7, confidence, max_iters)
-    best_iter, best_k, max_good, niters = (int(v) for v in res.cpu())
+
+    def solve_and_score(lo, hi):
+        models, nm = ops.solve_7pt(_h2d(subsets[lo:hi]), pts_d)          # (h,3,9), (h,)
+        valid = (torch.arange(3, device=nm.device, dtype=torch.int32)[None, :] < nm[:, None]).to(torch.uint8)
+        counts = ops.score_fund(models.reshape(-1, 9), pts_d, threshold, valid.reshape(-1))
+        return counts.reshape(-1, 3), nm, models
+
+    def replay(counts, nm):
+        return tuple(int(v) for v in ops.ransac_replay(counts, nm, n, 7, confidence, max_iters).cpu())
+
+    best_iter, best_k, max_good, niters, model = sharded_ransac(len(subsets), 3, 9, solve_and_score, replay, group)
     info.best_iter, info.best_model, info.max_good, info.niters = best_iter, best_k, max_good, niters
     if best_iter < 0 or max_good <= 0:
         return None, mask0, info
-    model = models[best_iter, best_k]
     mask = ops.mask_fund(model, pts_d, threshold)
     return model.reshape(3, 3).cpu().numpy(), mask.cpu().numpy().reshape(n, 1), info
 
 
 # ------------------------------------------------------------------------------- essential
-def find_essential_ransac(points1, points2, K, prob: float, threshold: float, max_iters: int
-                          ) -> Tuple[Optional[np.ndarray], Optional[np.ndarray], RansacInfo]:
+def find_essential_ransac(points1, points2, K, prob: float, threshold: float, max_iters: int,
+                          group=None) -> Tuple[Optional[np.ndarray], Optional[np.ndarray], RansacInfo]:
     """cv2.findEssentialMat(p1, p2, K, cv2.RANSAC, prob, threshold, max_iters)."""
     p1 = np.asarray(points1, dtype=np.float64).reshape(-1, 2)
     p2 = np.asarray(points2, dtype=np.float64).reshape(-1, 2)
@@ -124,23 +132,27 @@ def find_essential_ransac(points1, points2, K, prob: float, threshold: float, ma
     if len(subsets) == 0:
         return None, mask0, info
     pts_d = _h2d(x4)
-    models, nm = ops.solve_5pt(_h2d(subsets), pts_d)                     # (H,10,9)
-    H = models.shape[0]
-    valid = (torch.arange(10, device=nm.device, dtype=torch.int32)[None, :] < nm[:, None]).to(torch.uint8)
-    counts = ops.score_ess(models.reshape(H * 10, 9), pts_d, threshold, valid.reshape(-1))
-    res = ops.ransac_replay(counts.reshape(H, 10), nm, n, 5, prob, max_iters)
-    best_iter, best_k, max_good, niters = (int(v) for v in res.cpu())
+
+    def solve_and_score(lo, hi):
+        models, nm = ops.solve_5pt(_h2d(subsets[lo:hi]), pts_d)          # (h,10,9)
+        valid = (torch.arange(10, device=nm.device, dtype=torch.int32)[None, :] < nm[:, None]).to(torch.uint8)
+        counts = ops.score_ess(models.reshape(-1, 9), pts_d, threshold, valid.reshape(-1))
+        return counts.reshape(-1, 10), nm, models
+
+    def replay(counts, nm):
+        return tuple(int(v) for v in ops.ransac_replay(counts, nm, n, 5, prob, max_iters).cpu())
+
+    best_iter, best_k, max_good, niters, model = sharded_ransac(len(subsets), 10, 9, solve_and_score, replay, group)
     info.best_iter, info.best_model, info.max_good, info.niters = best_iter, best_k, max_good, niters
     if best_iter < 0 or max_good <= 0:
         return None, mask0, info
-    model = models[best_iter, best_k]
     mask = ops.mask_ess(model, pts_d, threshold)
     return model.reshape(3, 3).cpu().numpy(), mask.cpu().numpy().reshape(n, 1), info
 
 
 # ------------------------------------------------------------------------------- PnP
 def solve_pnp_ransac_p3p(object_points, image_points, K, iterations_count: int, reprojection_error: float,
-                         confidence: float):
+                         confidence: float, group=None):
     """cv.solvePnPRansac(obj, img, K, distCoeffs=0, flags=SOLVEPNP_P3P, ...).
 
     -> (ok, rvec (3,1) f64, tvec (3,1) f64, inliers (L,1) i32 | None, RansacInfo)
@@ -170,16 +182,22 @@ def solve_pnp_ransac_p3p(object_points, image_points, K, iterations_count: int, 
     info.n_generated = len(subsets)
     if len(subsets) == 0:
         return False, zeros, zeros.copy(), None, info
-    models, rvecs, nm = ops.solve_p3p(_h2d(subsets), obj_d, img_d, K)      # (H,12), (H,3), (H,)
-    counts = ops.score_pnp(models, obj_d, img_d, K, threshold, nm.to(torch.uint8))
-    res = ops.ransac_replay(counts, nm, n, 4, confidence, iterations_count)
-    best_iter, best_k, max_good, niters = (int(v) for v in res.cpu())
+
+    def solve_and_score(lo, hi):
+        models, rvecs, nm = ops.solve_p3p(_h2d(subsets[lo:hi]), obj_d, img_d, K)   # (h,12), (h,3), (h,)
+        counts = ops.score_pnp(models, obj_d, img_d, K, threshold, nm.to(torch.uint8))
+        return counts.reshape(-1, 1), nm, torch.cat([models, rvecs], dim=1).reshape(-1, 1, 15)
+
+    def replay(counts, nm):
+        return tuple(int(v) for v in ops.ransac_replay(counts, nm, n, 4, confidence, iterations_count).cpu())
+
+    best_iter, best_k, max_good, niters, packed = sharded_ransac(len(subsets), 1, 15, solve_and_score, replay, group)
     info.best_iter, info.best_model, info.max_good, info.niters = best_iter, best_k, max_good, niters
     if best_iter < 0 or max_good <= 0:
         return False, zeros, zeros.copy(), None, info
-    model = models[best_iter]
+    model = packed[:12].contiguous()
     mask = ops.mask_pnp(model, obj_d, img_d, K, threshold).cpu().numpy().astype(bool)
-    p3p_rvec = rvecs[best_iter].cpu().numpy().reshape(3, 1)
+    p3p_rvec = packed[12:].cpu().numpy().reshape(3, 1)
     p3p_tvec = model[9:].cpu().numpy().reshape(3, 1)
 
     # EPnP refit on the winner's inliers (serial, O(inliers), host): the pose OpenCV returns
