@@ -139,6 +139,28 @@ int vo_solve_p3p(const int32_t* samples, int H, const float* obj, const float* i
 int vo_ransac_replay(const int32_t* counts, const int32_t* nmodels, int n_iters, int max_models,
                      int n_points, int model_points, double confidence, int max_iters,
                      int32_t* result, void* stream);
+/* Whole RANSAC runs for `batch` problems of one shape, as four launches in total (solve, score,
+ * replay, mask) with no host round trip in between: the device-resident form of
+ *   kind 0: cv2.findFundamentalMat(..., cv2.RANSAC, ...)    reference src/utils/geometry.py:39
+ *   kind 1: cv2.findEssentialMat(..., cv2.RANSAC, ...)      reference src/utils/geometry.py:44
+ *   kind 2: cv.solvePnPRansac(..., SOLVEPNP_P3P, ...)       reference src/pnp.py:16-26 (without the
+ *           final EPnP refit, which is vo_host_epnp on the inliers)
+ * samples  batch x H x m int32 (m = 7 / 5 / 4), the getSubset stream of each problem
+ * pts      kind 0: batch x N x 4 f32; kind 1: batch x N x 4 f64 (K-normalised); kind 2: batch x N x 3 f32
+ *          object points, with img batch x N x 2 f32 and K4_host (img, K4_host unused otherwise)
+ * n_dev    optional batch x int32 on the device: correspondences actually present in each problem
+ *          (<= N, the array stride); NULL = N everywhere
+ * result   batch x 4 int32: best iteration (-1 none), best model, maxGood, final niters
+ * best_model batch x 9 (kinds 0, 1) or batch x 12 ([R|t], kind 2) f64; best_rvec batch x 3 f64 (kind 2,
+ *          may be NULL); mask batch x N uint8.  Scoring skips the empty model slots of samples with
+ *          fewer solutions than the maximum. */
+size_t vo_ransac_workspace_bytes(int kind, int H, int batch);
+int vo_ransac_batch(int kind, const int32_t* samples, int H, const void* pts, const float* img,
+                    const double* K4_host, int N, const int32_t* n_dev, int batch, float thr2,
+                    double confidence, int max_iters, int32_t* result, double* best_model,
+                    double* best_rvec, uint8_t* mask, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
 /* result (2 x int32): largest count and the lowest index holding it (pure argmax mode). */
 int vo_argmax_first(const int32_t* counts, int n, int32_t* result, void* stream);
 
@@ -158,6 +180,16 @@ int vo_host_update_num_iters(double p, double ep, int model_points, int max_iter
  * camera.  Returns 1 on success, 0 when no finite pose comes out, or a VO_E* code. */
 int vo_host_epnp(const double* obj_host, const double* img_host, int n, const double* K4_host,
                  double* R9_host, double* t3_host);
+
+/* ------------------------------------------------------------------------------------
+ * Measurement aid (no counterpart in the reference): HIP-event timing of single launches inside
+ * the entry points above, on the stream they run on.  stage_mask bits: 0 solve, 1 score, 2 replay,
+ * 3 mask (inside vo_ransac_batch; tag = kind), 4 the kNN sweep kernel (inside vo_knn2_l2_i8).
+ * vo_profile_enable(0, 0) switches it off.  vo_profile_collect waits for the recorded events and
+ * returns how many (tag, milliseconds) records it wrote; it resets the record list.
+ * ---------------------------------------------------------------------------------- */
+int vo_profile_enable(int stage_mask, int capacity);
+int vo_profile_collect(int32_t* tags_host, float* ms_host, int max_records);
 
 #ifdef __cplusplus
 }

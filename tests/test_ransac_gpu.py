@@ -230,3 +230,85 @@ def test_reference_level_functions(det_math, dev):
         assert np.allclose(T, oT, rtol=1e-6, atol=1e-9)
         assert np.squeeze(inl).ndim == 1          # usable as a fancy index, reference src/tracking.py:410-414
     params.which_dataset(0)
+
+
+# ---------------------------------------------------------------- fused batched pipeline
+def test_replay_long_and_batched(oracle_mod, dev):
+    """the parallel replay on tables longer than one 1024-entry step, several problems per launch"""
+    rng = np.random.default_rng(3)
+    B, n_it, mm = 5, 3000, 3
+    cnts = rng.integers(0, 60, size=(B, n_it, mm)).astype(np.int32)
+    nm = rng.integers(0, mm + 1, size=(B, n_it)).astype(np.int32)
+    cnts[1, 2500, 2] = 900; nm[1, 2500] = 3                    # late record, niters still large
+    cnts[2, 10, 0] = 2990; nm[2, 10] = 1                       # early near-perfect model: scan stops
+    cnts[3, np.arange(0, 3000, 7), 1] = np.arange(100, 100 + len(np.arange(0, 3000, 7)))  # many records
+    nm[3, np.arange(0, 3000, 7)] = 3
+    cnts[4] = 2
+    from visual_odometry_amd import _lib
+    lib = _lib.load()
+    for b in range(B):
+        res = ops.ransac_replay(_d(cnts[b], dev), _d(nm[b], dev), 3000, 7, 0.9999, n_it).cpu().numpy()
+        assert tuple(int(v) for v in res) == oracle_mod.ransac_replay(cnts[b], nm[b], 3000, 7, 0.9999, n_it), b
+
+
+@pytest.mark.parametrize("B,H,N", [(3, 512, 700), (1, 100, 2000), (6, 1100, 333)])
+def test_ransac_batch_fund_and_pnp(det_math, dev, B, H, N):
+    o = det_math
+    f_pts, f_sub, p_obj, p_img, p_sub = [], [], [], [], []
+    for b in range(B):
+        sc = synth.two_view_scene(N, seed=60 + b)
+        pts4 = np.concatenate([sc["p1"], sc["p2"]], 1).astype(np.float32)
+        f_pts.append(pts4); f_sub.append(ops.gen_subsets(N, 7, H, pts4))
+        ps = synth.pnp_scene(N, seed=80 + b)
+        p_obj.append(ps["obj"]); p_img.append(ps["img"]); p_sub.append(ops.gen_subsets(N, 4, H))
+    K = synth.K_MALAGA
+    res, best, _, mask = ops.ransac_batch(ops.KIND_FUND, _d(np.stack(f_sub), dev), _d(np.stack(f_pts), dev), 1.0, 0.999, H)
+    resp, bestp, rvp, maskp = ops.ransac_batch(ops.KIND_PNP, _d(np.stack(p_sub), dev), _d(np.stack(p_obj), dev), 2.0, 0.999, H,
+                                               img=_d(np.stack(p_img), dev), K=K)
+    res, best, mask = res.cpu().numpy(), best.cpu().numpy(), mask.cpu().numpy()
+    resp, bestp, rvp, maskp = resp.cpu().numpy(), bestp.cpu().numpy(), rvp.cpu().numpy(), maskp.cpu().numpy()
+    for b in range(B):
+        F, omask, info = o.find_fundamental_mat(f_pts[b][:, :2], f_pts[b][:, 2:], 1.0, 0.999, H)
+        assert tuple(res[b]) == tuple(int(v) for v in info)
+        assert np.array_equal(mask[b], omask.ravel()) and np.array_equal(best[b].reshape(3, 3), F)
+        # P3P stage of solvePnPRansac: compare decisions and the winning model with a by-hand oracle run
+        subs = p_sub[b]
+        cnts = np.zeros(H, np.int32); nm = np.zeros(H, np.int32); models = np.zeros((H, 12)); rvs = np.zeros((H, 3))
+        for h, s in enumerate(subs):
+            ns, rv, tv, R = o.p3p_kernel(p_obj[b][s], p_img[b][s], K)
+            if ns > 0:
+                nm[h] = 1; models[h] = np.concatenate([R.reshape(9), tv]); rvs[h] = rv
+                cnts[h] = o.find_inliers(o.pnp_error(R, tv, K, p_obj[b], p_img[b]), 2.0)[0]
+        exp = o.ransac_replay(cnts, nm, N, 4, 0.999, H)
+        assert tuple(resp[b]) == exp
+        if exp[0] >= 0:
+            m = models[exp[0]]
+            assert np.array_equal(bestp[b], m) and np.array_equal(rvp[b], rvs[exp[0]])
+            assert np.array_equal(maskp[b], o.find_inliers(o.pnp_error(m[:9], m[9:], K, p_obj[b], p_img[b]), 2.0)[1])
+
+
+def test_ransac_batch_ess_and_n_dev(det_math, dev):
+    o = det_math
+    B, H, N = 2, 150, 400
+    sc = [synth.two_view_scene(N, seed=90 + b) for b in range(B)]
+    K = sc[0]["K"]
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    x4s, subs = [], []
+    nvalid = [N, 250]                 # the second problem only uses its first 250 correspondences
+    for b in range(B):
+        p1, p2 = sc[b]["p1"].astype(np.float64), sc[b]["p2"].astype(np.float64)
+        x4 = np.stack([p1[:, 0] * (1 / fx) + (-cx * (1 / fx)), p1[:, 1] * (1 / fy) + (-cy * (1 / fy)),
+                       p2[:, 0] * (1 / fx) + (-cx * (1 / fx)), p2[:, 1] * (1 / fy) + (-cy * (1 / fy))], 1)
+        x4s.append(x4)
+        s = np.zeros((H, 5), np.int32); g = ops.gen_subsets(nvalid[b], 5, H); s[:len(g)] = g
+        subs.append(s)
+    thr = 1.0 / ((fx + fy) / 2)
+    res, best, _, mask = ops.ransac_batch(ops.KIND_ESS, _d(np.stack(subs), dev), _d(np.stack(x4s), dev), thr, 0.999, H,
+                                          n_dev=_d(np.array(nvalid, np.int32), dev))
+    res, best, mask = res.cpu().numpy(), best.cpu().numpy(), mask.cpu().numpy()
+    for b in range(B):
+        n = nvalid[b]
+        E, omask, info = o.find_essential_mat(sc[b]["p1"][:n], sc[b]["p2"][:n], K, 0.999, 1.0, H)
+        assert tuple(res[b]) == tuple(int(v) for v in info)
+        assert np.array_equal(best[b].reshape(3, 3), E)
+        assert np.array_equal(mask[b][:n], omask.ravel()) and not mask[b][n:].any()

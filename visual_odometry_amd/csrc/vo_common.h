@@ -31,3 +31,30 @@ void vo_set_error(const char* fmt, ...);
 #define VO_LAUNCH_CHECK() VO_HIP_TRY(hipGetLastError())
 
 static inline int vo_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- internal launchers shared between translation units (not part of the C ABI) ------------
+enum { VO_KIND_FUND = 0, VO_KIND_ESS = 1, VO_KIND_PNP = 2 };
+int vo_launch_init_counts(const uint8_t* valid, const int32_t* nmodels, int slots_per_sample, long total,
+                          int32_t* counts, hipStream_t s);
+int vo_launch_score(int kind, const double* models, const uint8_t* valid, const int32_t* list, const int32_t* nlist,
+                    int H, const void* pts, const float* img, const int32_t* n_dev, int N, int batch,
+                    const double* K4, float thr2, int32_t* counts, hipStream_t s);
+int vo_launch_mask_best(int kind, const double* models, int slots_per_problem, int slots_per_sample,
+                        const double* aux, int aux_w, double* best_aux, const int32_t* result, const void* pts,
+                        const float* img, const int32_t* n_dev, int N, int batch, const double* K4, float thr2,
+                        uint8_t* mask, double* best_model, hipStream_t s);
+int vo_launch_solve_7pt(const int32_t* samples, int H, int per, const float* pts, int N, const int32_t* n_dev,
+                        double* models, int32_t* nmodels, int32_t* list, int32_t* nlist, hipStream_t s);
+int vo_launch_solve_5pt(const int32_t* samples, int H, int per, const double* pts, int N, const int32_t* n_dev,
+                        double* models, int32_t* nmodels, int32_t* list, int32_t* nlist, hipStream_t s);
+int vo_launch_solve_p3p(const int32_t* samples, int H, int per, const float* obj, const float* img, const double* K4,
+                        int N, const int32_t* n_dev, double* models, double* rvecs, int32_t* nmodels, int32_t* list,
+                        int32_t* nlist, hipStream_t s);
+int vo_launch_replay(const int32_t* counts, const int32_t* nmodels, int n_iters, int max_models, int n_points,
+                     const int32_t* n_dev, int model_points, double confidence, int max_iters, int batch,
+                     int32_t* result, hipStream_t s);
+
+// timing aid (vo_runtime.hip): stage ids for vo_profile_enable's mask
+enum { VO_STAGE_SOLVE = 0, VO_STAGE_SCORE = 1, VO_STAGE_REPLAY = 2, VO_STAGE_MASK = 3, VO_STAGE_KNN = 4 };
+void vo_prof_begin(int stage, int tag, hipStream_t s);
+void vo_prof_end(int stage, hipStream_t s);

@@ -371,8 +371,10 @@ extern "C" int vo_knn2_l2_i8(const int8_t* q, const int32_t* qnorm, int nq,
     VO_CHECK_ARG(p.nsplit <= 65535, VO_ESIZE, "vo_knn2_l2_i8: too many train splits");
     int4* partial = (int4*)workspace;
     dim3 grid(p.nqb, p.nsplit, batch);
+    vo_prof_begin(VO_STAGE_KNN, 0, s);
     hipLaunchKernelGGL(knn2_partial_kernel, grid, dim3(kWgThreads), kLdsBytes, s, q, t, tnorm, nq, nt,
                        p.rows_per_split, p.nsplit, partial, qnorm, idx, d2);
+    vo_prof_end(VO_STAGE_KNN, s);
     VO_LAUNCH_CHECK();
     if (p.nsplit == 1) return VO_OK;
     hipLaunchKernelGGL(knn2_merge_kernel, dim3(vo_ceil_div(nq, 256), batch), dim3(256), 0, s, partial, qnorm,

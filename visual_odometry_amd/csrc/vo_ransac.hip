@@ -29,46 +29,94 @@ __host__ __device__ inline int update_num_iters(double p, double ep, int model_p
     return (int)rint(num / denom);          // cvRound: round half to even
 }
 
-// one wave; counts laid out [iter][model]; scans in (iter, model) order
-__global__ __launch_bounds__(64)
+// One workgroup (16 waves) per problem; counts laid out [iter][model] and visited in that order,
+// 1024 entries per step.  An entry is a "record" when it beats everything before it (and
+// modelPoints-1): exactly the entries the sequential loop would accept, as long as the loop is still
+// running.  Records of a step are found with a wave prefix-max + ballot and handed, in order, to
+// thread 0, which applies RANSACUpdateNumIters and stops the scan where OpenCV's loop would have.
+constexpr int kReplayThreads = 1024;
+
+__global__ __launch_bounds__(kReplayThreads)
 void ransac_replay_kernel(const int32_t* __restrict__ counts, const int32_t* __restrict__ nmodels,
-                          int n_iters, int max_models, int n_points, int model_points,
-                          double confidence, int max_iters, int32_t* __restrict__ result)
+                          int n_iters, int max_models, int n_points, const int32_t* __restrict__ n_dev,
+                          int model_points, double confidence, int max_iters, int32_t* __restrict__ result)
 {
-    const int lane = threadIdx.x;
-    int niters = max_iters > 1 ? max_iters : 1;
-    int max_good = 0, best_iter = -1, best_k = -1;
-    long pos = 0;                                         // flat index iter*max_models + k
-    for (;;) {
-        // "iter < niters" is only tested between iterations: the models of the iteration
-        // that produced the latest improvement are all scored even if niters just shrank
-        int lim_it = niters < n_iters ? niters : n_iters;
-        if (best_iter + 1 > lim_it) lim_it = best_iter + 1;
-        const long limit = (long)lim_it * max_models;
-        if (pos >= limit) break;
-        const long i = pos + lane;
-        const int floor_ = max_good > model_points - 1 ? max_good : model_points - 1;
-        bool hit = false;
-        int c = 0;
-        if (i < limit) {
-            const int it = (int)(i / max_models), k = (int)(i - (long)it * max_models);
-            c = counts[i];
-            const bool present = nmodels ? k < nmodels[it] : c >= 0;
-            hit = present && c > floor_;
-        }
-        const unsigned long long bal = __ballot(hit);
-        if (bal == 0) { pos += 64; continue; }
-        const int first = __ffsll((long long)bal) - 1;
-        const int good = __shfl(c, first);
-        const long at = pos + first;
-        max_good = good;
-        best_iter = (int)(at / max_models);
-        best_k = (int)(at - (long)best_iter * max_models);
-        niters = update_num_iters(confidence, (double)(n_points - good) / n_points, model_points, niters);
-        pos = at + 1;
+    __shared__ int s_wmax[16], s_wcnt[16];
+    __shared__ int2 s_rec[kReplayThreads];
+    __shared__ int s_niters, s_good, s_best_iter, s_best_k, s_stop;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const long len = (long)n_iters * max_models;
+    counts += (size_t)b * len;
+    if (nmodels) nmodels += (size_t)b * n_iters;
+    const int npts = n_dev ? n_dev[b] : n_points;
+    if (tid == 0) {
+        s_niters = max_iters > 1 ? max_iters : 1;
+        s_good = 0; s_best_iter = -1; s_best_k = -1;
+        s_stop = npts <= 0;
     }
-    if (lane == 0) {
-        result[0] = best_iter; result[1] = best_k; result[2] = max_good; result[3] = niters;
+    __syncthreads();
+    int carry = model_points - 1;                       // max over everything already visited
+    for (long base = 0; base < len; base += kReplayThreads) {
+        // "iter < niters" is tested between iterations only: the iteration that produced the
+        // latest improvement is always finished
+        const int it_first = (int)(base / max_models);
+        const int lim = s_niters < n_iters ? s_niters : n_iters;
+        if (s_stop || (it_first >= lim && it_first > s_best_iter)) break;
+        const long i = base + tid;
+        int v = INT32_MIN;
+        if (i < len) {
+            const int it = (int)(i / max_models), k = (int)(i - (long)it * max_models);
+            const int c = counts[i];
+            if (nmodels ? k < nmodels[it] : c >= 0) v = c;
+        }
+        int x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d);
+            if (lane >= d) x = x > y ? x : y;
+        }
+        if (lane == 63) s_wmax[wave] = x;
+        const int prev = __shfl_up(x, 1);
+        __syncthreads();
+        int before = carry, all = carry;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int m = s_wmax[w];
+            if (w < wave) before = before > m ? before : m;
+            all = all > m ? all : m;
+        }
+        if (lane > 0) before = before > prev ? before : prev;
+        const bool rec = v > before;
+        const unsigned long long bal = __ballot(rec);
+        if (lane == 0) s_wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = __popcll(bal & ((1ull << lane) - 1)), total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int c = s_wcnt[w];
+            if (w < wave) off += c;
+            total += c;
+        }
+        if (rec) s_rec[off] = make_int2((int)(i - base), v);
+        __syncthreads();
+        if (tid == 0 && total > 0) {
+            int niters = s_niters, good = s_good, best_iter = s_best_iter, best_k = s_best_k, stop = 0;
+            for (int r = 0; r < total; ++r) {
+                const long pos = base + s_rec[r].x;
+                const int it = (int)(pos / max_models), k = (int)(pos - (long)it * max_models);
+                const int l = niters < n_iters ? niters : n_iters;
+                if (!(it < l || it == best_iter)) { stop = 1; break; }
+                good = s_rec[r].y; best_iter = it; best_k = k;
+                niters = update_num_iters(confidence, (double)(npts - good) / npts, model_points, niters);
+            }
+            s_niters = niters; s_good = good; s_best_iter = best_iter; s_best_k = best_k; s_stop = stop;
+        }
+        __syncthreads();
+        carry = all;
+    }
+    if (tid == 0) {
+        int32_t* r = result + 4 * (size_t)b;
+        r[0] = s_best_iter; r[1] = s_best_k; r[2] = s_good; r[3] = s_niters;
     }
 }
 
@@ -131,6 +179,97 @@ bool collinear_last(const float* pts4, const int32_t* idx, int count, int off)
 
 }  // namespace
 
+int vo_launch_replay(const int32_t* counts, const int32_t* nmodels, int n_iters, int max_models, int n_points,
+                     const int32_t* n_dev, int model_points, double confidence, int max_iters, int batch,
+                     int32_t* result, hipStream_t s)
+{
+    if (batch == 0) return VO_OK;
+    hipLaunchKernelGGL(ransac_replay_kernel, dim3(batch), dim3(kReplayThreads), 0, s, counts, nmodels, n_iters,
+                       max_models, n_points, n_dev, model_points, confidence, max_iters, result);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}
+
+// ---- fused batched pipelines: solve -> score -> replay -> mask for `batch` problems of one shape --
+namespace {
+struct RansacWs {
+    double* models; double* aux; int32_t* nmodels; int32_t* counts; int32_t* list; int32_t* nlist;
+    size_t bytes;
+};
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+RansacWs carve(void* base, int width, int mw, int aux_w, int H, int batch)
+{
+    RansacWs w;
+    size_t off = 0;
+    char* p = (char*)base;
+    const size_t slots = (size_t)batch * H * width;
+    w.models = (double*)(p + off); off += align_up(slots * mw * sizeof(double));
+    w.aux = (double*)(p + off); off += align_up(slots * aux_w * sizeof(double));
+    w.nmodels = (int32_t*)(p + off); off += align_up((size_t)batch * H * sizeof(int32_t));
+    w.counts = (int32_t*)(p + off); off += align_up(slots * sizeof(int32_t));
+    w.list = (int32_t*)(p + off); off += align_up(slots * sizeof(int32_t));
+    w.nlist = (int32_t*)(p + off); off += align_up((size_t)batch * sizeof(int32_t));
+    w.bytes = off;
+    return w;
+}
+const int kWidth[3] = {3, 10, 1}, kMw[3] = {9, 9, 12}, kAux[3] = {0, 0, 3}, kModelPoints[3] = {7, 5, 4};
+}  // namespace
+
+extern "C" size_t vo_ransac_workspace_bytes(int kind, int H, int batch)
+{
+    if (kind < 0 || kind > 2 || H <= 0 || batch <= 0) return 256;
+    return carve(nullptr, kWidth[kind], kMw[kind], kAux[kind], H, batch).bytes;
+}
+
+extern "C" int vo_ransac_batch(int kind, const int32_t* samples, int H, const void* pts, const float* img,
+                               const double* K4_host, int N, const int32_t* n_dev, int batch, float thr2,
+                               double confidence, int max_iters, int32_t* result, double* best_model,
+                               double* best_rvec, uint8_t* mask, void* workspace, size_t workspace_bytes,
+                               void* stream)
+{
+    VO_CHECK_ARG(kind >= 0 && kind <= 2, VO_EINVAL, "vo_ransac_batch: kind must be 0 (F), 1 (E) or 2 (PnP)");
+    VO_CHECK_ARG(H >= 0 && N >= 0 && batch >= 0, VO_EINVAL, "vo_ransac_batch: negative size");
+    if (batch == 0) return VO_OK;
+    VO_CHECK_ARG(H > 0 && N > 0, VO_EINVAL, "vo_ransac_batch: needs at least one sample and one correspondence");
+    VO_CHECK_ARG(samples && pts && result && mask, VO_EINVAL, "vo_ransac_batch: null pointer");
+    VO_CHECK_ARG(kind != VO_KIND_PNP || (img && K4_host && ((uintptr_t)img & 7) == 0), VO_EINVAL,
+                 "vo_ransac_batch: PnP needs img (8-byte aligned) and K4_host");
+    VO_CHECK_ARG(kind != VO_KIND_FUND || ((uintptr_t)pts & 15) == 0, VO_EINVAL, "vo_ransac_batch: pts must be 16-byte aligned");
+    VO_CHECK_ARG(confidence > 0 && confidence < 1, VO_EINVAL, "vo_ransac_batch: confidence must be in (0,1)");
+    VO_CHECK_ARG((long)H * batch <= 2147483647L / 16 && batch <= 65535, VO_ESIZE, "vo_ransac_batch: H x batch too large");
+    const int width = kWidth[kind], mw = kMw[kind], aux_w = kAux[kind];
+    const RansacWs w = carve(workspace, width, mw, aux_w, H, batch);
+    VO_CHECK_ARG(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= w.bytes, VO_EWORKSPACE,
+                 "vo_ransac_batch: workspace of %zu bytes (16-byte aligned) required, got %zu", w.bytes, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    VO_HIP_TRY(hipMemsetAsync(w.nlist, 0, (size_t)batch * sizeof(int32_t), s));
+    const int Htot = H * batch;
+    int rc;
+    vo_prof_begin(VO_STAGE_SOLVE, kind, s);
+    if (kind == VO_KIND_FUND)
+        rc = vo_launch_solve_7pt(samples, Htot, H, (const float*)pts, N, n_dev, w.models, w.nmodels, w.list, w.nlist, s);
+    else if (kind == VO_KIND_ESS)
+        rc = vo_launch_solve_5pt(samples, Htot, H, (const double*)pts, N, n_dev, w.models, w.nmodels, w.list, w.nlist, s);
+    else
+        rc = vo_launch_solve_p3p(samples, Htot, H, (const float*)pts, img, K4_host, N, n_dev, w.models, w.aux, w.nmodels,
+                                 w.list, w.nlist, s);
+    vo_prof_end(VO_STAGE_SOLVE, s);
+    if (rc != VO_OK) return rc;
+    rc = vo_launch_init_counts(nullptr, w.nmodels, width, (long)Htot * width, w.counts, s);
+    if (rc != VO_OK) return rc;
+    vo_prof_begin(VO_STAGE_SCORE, kind, s);
+    rc = vo_launch_score(kind, w.models, nullptr, w.list, w.nlist, H * width, pts, img, n_dev, N, batch, K4_host, thr2,
+                         w.counts, s);
+    vo_prof_end(VO_STAGE_SCORE, s);
+    if (rc != VO_OK) return rc;
+    vo_prof_begin(VO_STAGE_REPLAY, kind, s);
+    rc = vo_launch_replay(w.counts, w.nmodels, H, width, N, n_dev, kModelPoints[kind], confidence, max_iters, batch, result, s);
+    vo_prof_end(VO_STAGE_REPLAY, s);
+    if (rc != VO_OK) return rc;
+    return vo_launch_mask_best(kind, w.models, H * width, width, aux_w ? w.aux : nullptr, aux_w, best_rvec, result, pts, img,
+                               n_dev, N, batch, K4_host, thr2, mask, best_model, s);
+}
+
 extern "C" int vo_ransac_replay(const int32_t* counts, const int32_t* nmodels, int n_iters, int max_models,
                                 int n_points, int model_points, double confidence, int max_iters,
                                 int32_t* result, void* stream)
@@ -139,10 +278,8 @@ extern "C" int vo_ransac_replay(const int32_t* counts, const int32_t* nmodels, i
                  "vo_ransac_replay: bad sizes");
     VO_CHECK_ARG(result && (counts || n_iters == 0), VO_EINVAL, "vo_ransac_replay: null pointer");
     VO_CHECK_ARG(confidence > 0 && confidence < 1, VO_EINVAL, "vo_ransac_replay: confidence must be in (0,1)");
-    hipLaunchKernelGGL(ransac_replay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counts, nmodels, n_iters,
-                       max_models, n_points, model_points, confidence, max_iters, result);
-    VO_LAUNCH_CHECK();
-    return VO_OK;
+    return vo_launch_replay(counts, nmodels, n_iters, max_models, n_points, nullptr, model_points, confidence, max_iters,
+                            1, result, (hipStream_t)stream);
 }
 
 extern "C" int vo_argmax_first(const int32_t* counts, int n, int32_t* result, void* stream)

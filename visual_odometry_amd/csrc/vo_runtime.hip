@@ -51,3 +51,58 @@ extern "C" int vo_device_check(int device)
     }
     return VO_OK;
 }
+
+// ---- optional in-library timing of single launches inside the fused entry points --------------
+// bench.py needs the duration of ONE kernel (the scoring launch) inside vo_ransac_batch, measured
+// with HIP events on the stream the kernel runs on.  Disabled (zero cost beyond one branch) unless
+// vo_profile_enable() was called.  Not thread-safe: a measurement aid, not a data path.
+#include <vector>
+namespace {
+struct ProfRec { int tag; hipEvent_t e0, e1; };
+std::vector<ProfRec> g_prof;
+size_t g_prof_used = 0;
+int g_prof_mask = 0;
+}  // namespace
+
+void vo_prof_begin(int stage, int tag, hipStream_t s)
+{
+    if (!(g_prof_mask & (1 << stage)) || g_prof_used >= g_prof.size()) return;
+    g_prof[g_prof_used].tag = tag;
+    (void)hipEventRecord(g_prof[g_prof_used].e0, s);
+}
+
+void vo_prof_end(int stage, hipStream_t s)
+{
+    if (!(g_prof_mask & (1 << stage)) || g_prof_used >= g_prof.size()) return;
+    (void)hipEventRecord(g_prof[g_prof_used].e1, s);
+    ++g_prof_used;
+}
+
+extern "C" int vo_profile_enable(int stage_mask, int capacity)
+{
+    VO_CHECK_ARG(capacity >= 0 && capacity <= (1 << 20), VO_EINVAL, "vo_profile_enable: bad capacity");
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_prof.clear();
+    g_prof_used = 0;
+    g_prof_mask = stage_mask;
+    if (stage_mask == 0) return VO_OK;
+    g_prof.resize(capacity);
+    for (auto& r : g_prof) {
+        VO_HIP_TRY(hipEventCreate(&r.e0));
+        VO_HIP_TRY(hipEventCreate(&r.e1));
+    }
+    return VO_OK;
+}
+
+extern "C" int vo_profile_collect(int32_t* tags_host, float* ms_host, int max_records)
+{
+    VO_CHECK_ARG(max_records >= 0 && (max_records == 0 || (tags_host && ms_host)), VO_EINVAL, "vo_profile_collect: bad arguments");
+    int n = 0;
+    for (size_t i = 0; i < g_prof_used && n < max_records; ++i, ++n) {
+        VO_HIP_TRY(hipEventSynchronize(g_prof[i].e1));
+        VO_HIP_TRY(hipEventElapsedTime(&ms_host[n], g_prof[i].e0, g_prof[i].e1));
+        tags_host[n] = g_prof[i].tag;
+    }
+    g_prof_used = 0;
+    return n;
+}

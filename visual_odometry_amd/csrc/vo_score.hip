@@ -73,88 +73,89 @@ __device__ __forceinline__ float pnp_err(const double* M, double fx, double fy, 
     return s;
 }
 
-__global__ void init_counts_kernel(const uint8_t* __restrict__ valid, int H, int32_t* __restrict__ counts)
+// counts[b][slot] = 0 where a model exists (valid byte, or slot%slots_per_sample < nmodels), else -1
+__global__ void init_counts_kernel(const uint8_t* __restrict__ valid, const int32_t* __restrict__ nmodels,
+                                   int slots_per_sample, int total, int32_t* __restrict__ counts)
 {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h < H) counts[h] = (valid && !valid[h]) ? -1 : 0;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    bool ok = true;
+    if (valid) ok = valid[i] != 0;
+    else if (nmodels) ok = (i % slots_per_sample) < nmodels[i / slots_per_sample];
+    counts[i] = ok ? 0 : -1;
 }
 
-// ---- count kernels ------------------------------------------------------------------------
+// ---- count kernel (one template for the three error functions) -----------------------------
+enum { kFund = 0, kEss = 1, kPnp = 2 };
 
+struct ScoreArgs {
+    const double* models;     // batch x H x MW f64
+    const uint8_t* valid;     // batch x H, may be null
+    const int32_t* list;      // batch x H compacted slot list, may be null (then thread t scores slot t)
+    const int32_t* nlist;     // batch entries used of list
+    const void* pts;          // F: batch x N float4; E: batch x N x 4 f64; PnP: batch x N x 3 f32
+    const float2* img;        // PnP only: batch x N
+    const int32_t* n_dev;     // per-problem correspondence count (<= N), may be null
+    int32_t* counts;          // batch x H
+    int H, N, chunk;
+    float thr2;
+    double fx, fy, cx, cy;
+};
+
+template <int KIND>
 __global__ __launch_bounds__(kThreads)
-void score_fund_kernel(const double* __restrict__ models, const uint8_t* __restrict__ valid, int H,
-                       const float4* __restrict__ pts, int N, int chunk, float thr2,
-                       int32_t* __restrict__ counts)
+void score_kernel(const ScoreArgs a)
 {
+    constexpr int MW = KIND == kPnp ? 12 : 9;
     __shared__ __attribute__((aligned(16))) double sp[kMaxChunk * 4];
-    const int h = blockIdx.x * kThreads + threadIdx.x;
-    const int p0 = blockIdx.y * chunk, np = min(chunk, N - p0);
-    for (int i = threadIdx.x; i < np; i += kThreads) {
-        const float4 v = pts[p0 + i];
-        sp[4 * i] = v.x; sp[4 * i + 1] = v.y; sp[4 * i + 2] = v.z; sp[4 * i + 3] = v.w;
-    }
-    const bool live = h < H && (!valid || valid[h]);
-    double F[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) F[k] = live ? models[(size_t)h * 9 + k] : 0.;
-    __syncthreads();
-    int cnt = 0;
-    for (int i = 0; i < np; ++i) {
-        const double2 a = *(const double2*)(sp + 4 * i), b = *(const double2*)(sp + 4 * i + 2);
-        cnt += fund_err(F, a.x, a.y, b.x, b.y) <= thr2;
-    }
-    if (live && cnt) atomicAdd(counts + h, cnt);
-}
+    const int b = blockIdx.z;
+    const int n = a.n_dev ? min(a.n_dev[b], a.N) : a.N;
+    const int p0 = blockIdx.y * a.chunk;
+    const int nslots = a.list ? a.nlist[b] : a.H;
+    if (p0 >= n || (int)(blockIdx.x * kThreads) >= nslots) return;      // block-uniform
+    const int np = min(a.chunk, n - p0);
 
-__global__ __launch_bounds__(kThreads)
-void score_ess_kernel(const double* __restrict__ models, const uint8_t* __restrict__ valid, int H,
-                      const double* __restrict__ pts, int N, int chunk, float thr2,
-                      int32_t* __restrict__ counts)
-{
-    __shared__ __attribute__((aligned(16))) double sp[kMaxChunk * 4];
-    const int h = blockIdx.x * kThreads + threadIdx.x;
-    const int p0 = blockIdx.y * chunk, np = min(chunk, N - p0);
-    for (int i = threadIdx.x; i < np * 4; i += kThreads) sp[i] = pts[(size_t)p0 * 4 + i];
-    const bool live = h < H && (!valid || valid[h]);
-    double E[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) E[k] = live ? models[(size_t)h * 9 + k] : 0.;
-    __syncthreads();
-    int cnt = 0;
-    for (int i = 0; i < np; ++i) {
-        const double2 a = *(const double2*)(sp + 4 * i), b = *(const double2*)(sp + 4 * i + 2);
-        cnt += sampson_err(E, a.x, a.y, b.x, b.y) <= thr2;
+    if (KIND == kFund) {
+        const float4* pts = (const float4*)a.pts + (size_t)b * a.N + p0;
+        for (int i = threadIdx.x; i < np; i += kThreads) {
+            const float4 v = pts[i];
+            sp[4 * i] = v.x; sp[4 * i + 1] = v.y; sp[4 * i + 2] = v.z; sp[4 * i + 3] = v.w;
+        }
+    } else if (KIND == kEss) {
+        const double* pts = (const double*)a.pts + ((size_t)b * a.N + p0) * 4;
+        for (int i = threadIdx.x; i < np * 4; i += kThreads) sp[i] = pts[i];
+    } else {
+        const float* obj = (const float*)a.pts + ((size_t)b * a.N + p0) * 3;
+        const float2* img = a.img + (size_t)b * a.N + p0;
+        for (int i = threadIdx.x; i < np; i += kThreads) {
+            sp[4 * i] = obj[3 * i]; sp[4 * i + 1] = obj[3 * i + 1]; sp[4 * i + 2] = obj[3 * i + 2];
+            *(float2*)(sp + 4 * i + 3) = img[i];
+        }
     }
-    if (live && cnt) atomicAdd(counts + h, cnt);
-}
 
-__global__ __launch_bounds__(kThreads)
-void score_pnp_kernel(const double* __restrict__ models, const uint8_t* __restrict__ valid, int H,
-                      const float* __restrict__ obj, const float2* __restrict__ img, int N, int chunk,
-                      double fx, double fy, double cx, double cy, float thr2,
-                      int32_t* __restrict__ counts)
-{
-    __shared__ __attribute__((aligned(16))) double sp[kMaxChunk * 4];   // X Y Z (u,v as 2 x f32)
-    const int h = blockIdx.x * kThreads + threadIdx.x;
-    const int p0 = blockIdx.y * chunk, np = min(chunk, N - p0);
-    for (int i = threadIdx.x; i < np; i += kThreads) {
-        const float* o = obj + (size_t)(p0 + i) * 3;
-        sp[4 * i] = o[0]; sp[4 * i + 1] = o[1]; sp[4 * i + 2] = o[2];
-        *(float2*)(sp + 4 * i + 3) = img[p0 + i];
-    }
-    const bool live = h < H && (!valid || valid[h]);
-    double M[12];
+    const int t = blockIdx.x * kThreads + threadIdx.x;
+    int slot = t;
+    bool live = t < nslots;
+    if (a.list) slot = live ? a.list[(size_t)b * a.H + t] : 0;
+    const size_t gslot = (size_t)b * a.H + slot;
+    if (!a.list) live = live && (!a.valid || a.valid[gslot]);
+    double M[MW];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) M[k] = live ? models[(size_t)h * 12 + k] : 0.;
+    for (int k = 0; k < MW; ++k) M[k] = live ? a.models[gslot * MW + k] : 0.;
     __syncthreads();
     int cnt = 0;
     for (int i = 0; i < np; ++i) {
-        const double2 a = *(const double2*)(sp + 4 * i);
-        const double Z = sp[4 * i + 2];
-        const float2 uv = *(const float2*)(sp + 4 * i + 3);
-        cnt += pnp_err(M, fx, fy, cx, cy, a.x, a.y, Z, uv.x, uv.y) <= thr2;
+        const double2 u = *(const double2*)(sp + 4 * i);
+        if (KIND == kPnp) {
+            const double Z = sp[4 * i + 2];
+            const float2 uv = *(const float2*)(sp + 4 * i + 3);
+            cnt += pnp_err(M, a.fx, a.fy, a.cx, a.cy, u.x, u.y, Z, uv.x, uv.y) <= a.thr2;
+        } else {
+            const double2 v = *(const double2*)(sp + 4 * i + 2);
+            cnt += (KIND == kFund ? fund_err(M, u.x, u.y, v.x, v.y) : sampson_err(M, u.x, u.y, v.x, v.y)) <= a.thr2;
+        }
     }
-    if (live && cnt) atomicAdd(counts + h, cnt);
+    if (live && cnt) atomicAdd(a.counts + gslot, cnt);
 }
 
 // ---- mask kernels (one model, thread per correspondence) ----------------------------------
@@ -197,26 +198,125 @@ __global__ void mask_pnp_kernel(const double* __restrict__ model, const float* _
     mask[i] = pnp_err(M, fx, fy, cx, cy, o[0], o[1], o[2], uv.x, uv.y) <= thr2;
 }
 
-int pick_chunk(int H, int N)
+// Mask of the model the replay chose, for a batch of problems: result[b] = {best_iter, best_model, ...}
+// addresses the model table directly, so no host round trip sits between replay and mask.
+struct MaskArgs {
+    const double* models;      // batch x slots_per_problem x MW
+    const int32_t* result;     // batch x 4
+    const void* pts;
+    const float2* img;
+    const int32_t* n_dev;
+    uint8_t* mask;             // batch x N
+    double* best_model;        // batch x MW, may be null
+    const double* aux;         // batch x (slots_per_problem) x aux_w, may be null (P3P rotation vectors)
+    double* best_aux;          // batch x aux_w
+    int slots_per_problem, slots_per_sample, aux_w, N;
+    float thr2;
+    double fx, fy, cx, cy;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(256)
+void mask_best_kernel(const MaskArgs a)
 {
-    const int mblocks = vo_ceil_div(H, kThreads);
-    const int target = 2048;                      // ~8 workgroups of 4 waves per CU
-    int per = vo_ceil_div(target, mblocks);       // chunks wanted along N
-    int chunk = vo_ceil_div(N, per);
+    constexpr int MW = KIND == kPnp ? 12 : 9;
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = a.n_dev ? min(a.n_dev[b], a.N) : a.N;
+    const int best_iter = a.result[4 * b], best_k = a.result[4 * b + 1];
+    const bool have = best_iter >= 0 && best_k >= 0;
+    const size_t slot = (size_t)b * a.slots_per_problem + (have ? best_iter * a.slots_per_sample + best_k : 0);
+    double M[MW];
+#pragma unroll
+    for (int k = 0; k < MW; ++k) M[k] = have ? a.models[slot * MW + k] : 0.;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (a.best_model)
+            for (int k = 0; k < MW; ++k) a.best_model[(size_t)b * MW + k] = M[k];
+        if (a.aux && a.best_aux)
+            for (int k = 0; k < a.aux_w; ++k) a.best_aux[(size_t)b * a.aux_w + k] = have ? a.aux[slot * a.aux_w + k] : 0.;
+    }
+    if (i >= a.N) return;
+    uint8_t m = 0;
+    if (have && i < n) {
+        const size_t gi = (size_t)b * a.N + i;
+        if (KIND == kFund) {
+            const float4 v = ((const float4*)a.pts)[gi];
+            m = fund_err(M, v.x, v.y, v.z, v.w) <= a.thr2;
+        } else if (KIND == kEss) {
+            const double* p = (const double*)a.pts + gi * 4;
+            m = sampson_err(M, p[0], p[1], p[2], p[3]) <= a.thr2;
+        } else {
+            const float* o = (const float*)a.pts + gi * 3;
+            const float2 uv = a.img[gi];
+            m = pnp_err(M, a.fx, a.fy, a.cx, a.cy, o[0], o[1], o[2], uv.x, uv.y) <= a.thr2;
+        }
+    }
+    a.mask[(size_t)b * a.N + i] = m;
+}
+
+int pick_chunk(int H, int N, int batch)
+{
+    const long mblocks = (long)vo_ceil_div(H, kThreads) * batch;
+    const long target = 2048;                     // ~8 workgroups of 4 waves per CU
+    long per = (target + mblocks - 1) / mblocks;  // chunks wanted along N
+    if (per < 1) per = 1;
+    int chunk = vo_ceil_div(N, (int)per);
     chunk = vo_ceil_div(chunk, 32) * 32;
     if (chunk < 32) chunk = 32;
     if (chunk > kMaxChunk) chunk = kMaxChunk;
     return chunk;
 }
 
-int launch_init(const uint8_t* valid, int H, int32_t* counts, hipStream_t s)
+}  // namespace
+
+// shared with vo_ransac.hip (the fused batched pipelines)
+int vo_launch_init_counts(const uint8_t* valid, const int32_t* nmodels, int slots_per_sample, long total,
+                          int32_t* counts, hipStream_t s)
 {
-    hipLaunchKernelGGL(init_counts_kernel, dim3(vo_ceil_div(H, 256)), dim3(256), 0, s, valid, H, counts);
+    VO_CHECK_ARG(total <= 2147483647L, VO_ESIZE, "too many model slots");
+    if (total == 0) return VO_OK;
+    hipLaunchKernelGGL(init_counts_kernel, dim3(vo_ceil_div((int)total, 256)), dim3(256), 0, s, valid, nmodels,
+                       slots_per_sample, (int)total, counts);
     VO_LAUNCH_CHECK();
     return VO_OK;
 }
 
-}  // namespace
+int vo_launch_score(int kind, const double* models, const uint8_t* valid, const int32_t* list, const int32_t* nlist,
+                    int H, const void* pts, const float* img, const int32_t* n_dev, int N, int batch,
+                    const double* K4, float thr2, int32_t* counts, hipStream_t s)
+{
+    if (H == 0 || N == 0 || batch == 0) return VO_OK;
+    ScoreArgs a;
+    a.models = models; a.valid = valid; a.list = list; a.nlist = nlist; a.pts = pts; a.img = (const float2*)img;
+    a.n_dev = n_dev; a.counts = counts; a.H = H; a.N = N; a.thr2 = thr2;
+    a.chunk = pick_chunk(H, N, batch);
+    a.fx = K4 ? K4[0] : 0; a.fy = K4 ? K4[1] : 0; a.cx = K4 ? K4[2] : 0; a.cy = K4 ? K4[3] : 0;
+    VO_CHECK_ARG(vo_ceil_div(N, a.chunk) <= 65535 && batch <= 65535, VO_ESIZE, "score: N=%d or batch=%d too large", N, batch);
+    const dim3 grid(vo_ceil_div(H, kThreads), vo_ceil_div(N, a.chunk), batch);
+    if (kind == kFund) hipLaunchKernelGGL(score_kernel<kFund>, grid, dim3(kThreads), 0, s, a);
+    else if (kind == kEss) hipLaunchKernelGGL(score_kernel<kEss>, grid, dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL(score_kernel<kPnp>, grid, dim3(kThreads), 0, s, a);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}
+
+int vo_launch_mask_best(int kind, const double* models, int slots_per_problem, int slots_per_sample,
+                        const double* aux, int aux_w, double* best_aux, const int32_t* result, const void* pts,
+                        const float* img, const int32_t* n_dev, int N, int batch, const double* K4, float thr2,
+                        uint8_t* mask, double* best_model, hipStream_t s)
+{
+    if (batch == 0) return VO_OK;
+    MaskArgs a;
+    a.models = models; a.result = result; a.pts = pts; a.img = (const float2*)img; a.n_dev = n_dev; a.mask = mask;
+    a.best_model = best_model; a.aux = aux; a.best_aux = best_aux; a.aux_w = aux_w;
+    a.slots_per_problem = slots_per_problem; a.slots_per_sample = slots_per_sample; a.N = N; a.thr2 = thr2;
+    a.fx = K4 ? K4[0] : 0; a.fy = K4 ? K4[1] : 0; a.cx = K4 ? K4[2] : 0; a.cy = K4 ? K4[3] : 0;
+    const dim3 grid(vo_ceil_div(N > 0 ? N : 1, 256), batch);
+    if (kind == kFund) hipLaunchKernelGGL(mask_best_kernel<kFund>, grid, dim3(256), 0, s, a);
+    else if (kind == kEss) hipLaunchKernelGGL(mask_best_kernel<kEss>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(mask_best_kernel<kPnp>, grid, dim3(256), 0, s, a);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}
 
 #define SCORE_ARG_CHECKS(name)                                                                    \
     VO_CHECK_ARG(H >= 0 && N >= 0, VO_EINVAL, name ": negative size");                            \
@@ -229,15 +329,10 @@ extern "C" int vo_score_fund(const double* models, const uint8_t* valid, int H, 
 {
     SCORE_ARG_CHECKS("vo_score_fund");
     hipStream_t s = (hipStream_t)stream;
-    int rc = launch_init(valid, H, counts, s);
+    int rc = vo_launch_init_counts(valid, nullptr, 1, H, counts, s);
     if (rc != VO_OK || N == 0) return rc;
     VO_CHECK_ARG(pts && ((uintptr_t)pts & 15) == 0, VO_EINVAL, "vo_score_fund: pts null or not 16-byte aligned");
-    const int chunk = pick_chunk(H, N);
-    VO_CHECK_ARG(vo_ceil_div(N, chunk) <= 65535, VO_ESIZE, "vo_score_fund: N=%d too large", N);
-    hipLaunchKernelGGL(score_fund_kernel, dim3(vo_ceil_div(H, kThreads), vo_ceil_div(N, chunk)), dim3(kThreads),
-                       0, s, models, valid, H, (const float4*)pts, N, chunk, thr2, counts);
-    VO_LAUNCH_CHECK();
-    return VO_OK;
+    return vo_launch_score(kFund, models, valid, nullptr, nullptr, H, pts, nullptr, nullptr, N, 1, nullptr, thr2, counts, s);
 }
 
 extern "C" int vo_score_ess(const double* models, const uint8_t* valid, int H, const double* pts, int N,
@@ -245,15 +340,10 @@ extern "C" int vo_score_ess(const double* models, const uint8_t* valid, int H, c
 {
     SCORE_ARG_CHECKS("vo_score_ess");
     hipStream_t s = (hipStream_t)stream;
-    int rc = launch_init(valid, H, counts, s);
+    int rc = vo_launch_init_counts(valid, nullptr, 1, H, counts, s);
     if (rc != VO_OK || N == 0) return rc;
     VO_CHECK_ARG(pts != nullptr, VO_EINVAL, "vo_score_ess: null pts");
-    const int chunk = pick_chunk(H, N);
-    VO_CHECK_ARG(vo_ceil_div(N, chunk) <= 65535, VO_ESIZE, "vo_score_ess: N=%d too large", N);
-    hipLaunchKernelGGL(score_ess_kernel, dim3(vo_ceil_div(H, kThreads), vo_ceil_div(N, chunk)), dim3(kThreads),
-                       0, s, models, valid, H, pts, N, chunk, thr2, counts);
-    VO_LAUNCH_CHECK();
-    return VO_OK;
+    return vo_launch_score(kEss, models, valid, nullptr, nullptr, H, pts, nullptr, nullptr, N, 1, nullptr, thr2, counts, s);
 }
 
 extern "C" int vo_score_pnp(const double* models, const uint8_t* valid, int H, const float* obj,
@@ -262,17 +352,11 @@ extern "C" int vo_score_pnp(const double* models, const uint8_t* valid, int H, c
 {
     SCORE_ARG_CHECKS("vo_score_pnp");
     hipStream_t s = (hipStream_t)stream;
-    int rc = launch_init(valid, H, counts, s);
+    int rc = vo_launch_init_counts(valid, nullptr, 1, H, counts, s);
     if (rc != VO_OK || N == 0) return rc;
     VO_CHECK_ARG(obj && img && K4_host, VO_EINVAL, "vo_score_pnp: null pointer");
     VO_CHECK_ARG(((uintptr_t)img & 7) == 0, VO_EINVAL, "vo_score_pnp: img must be 8-byte aligned");
-    const int chunk = pick_chunk(H, N);
-    VO_CHECK_ARG(vo_ceil_div(N, chunk) <= 65535, VO_ESIZE, "vo_score_pnp: N=%d too large", N);
-    hipLaunchKernelGGL(score_pnp_kernel, dim3(vo_ceil_div(H, kThreads), vo_ceil_div(N, chunk)), dim3(kThreads),
-                       0, s, models, valid, H, obj, (const float2*)img, N, chunk, K4_host[0], K4_host[1],
-                       K4_host[2], K4_host[3], thr2, counts);
-    VO_LAUNCH_CHECK();
-    return VO_OK;
+    return vo_launch_score(kPnp, models, valid, nullptr, nullptr, H, obj, img, nullptr, N, 1, K4_host, thr2, counts, s);
 }
 
 extern "C" int vo_mask_fund(const double* model, const float* pts, int N, float thr2, uint8_t* mask, void* stream)

@@ -19,6 +19,18 @@ namespace {
 constexpr int kLanes = 64;          // one wave per workgroup, one sample per lane
 constexpr double kPi = 3.1415926535897932384626433832795;
 
+// Compacted list of the model slots that hold a model, per problem: the scoring kernel then
+// spends no lanes on the empty slots of samples with fewer than `width` solutions.  The order of
+// the list depends on atomic arrival order; nothing downstream depends on it (counts land in
+// their slot).
+__device__ __forceinline__ void append_slots(int32_t* list, int32_t* nlist, int b, int local_h, int per,
+                                             int width, int n)
+{
+    if (!list || n <= 0) return;
+    const int base = atomicAdd(nlist + b, n);
+    for (int k = 0; k < n; ++k) list[(size_t)b * per * width + base + k] = local_h * width + k;
+}
+
 struct SV {                         // element-major per-lane view into LDS
     double* p;
     __device__ __forceinline__ double& operator[](int i) const { return p[i * kLanes]; }
@@ -181,16 +193,20 @@ __device__ int solve_cubic(double a0, double a1, double a2, double a3, double* r
 // ------------------------------------------------------------------------------ 7-point
 __global__ __launch_bounds__(kLanes)
 void solve_7pt_kernel(const int32_t* __restrict__ samples, int H, const float4* __restrict__ pts, int N,
-                      double* __restrict__ models, int32_t* __restrict__ nmodels)
+                      double* __restrict__ models, int32_t* __restrict__ nmodels,
+                      int per, int32_t* __restrict__ list, int32_t* __restrict__ nlist, const int32_t* __restrict__ n_dev)
 {
     __shared__ double lds[(81 + 9) * kLanes];
     const int h = blockIdx.x * kLanes + threadIdx.x;
     const bool live = h < H;
+    const int b = live ? h / per : 0;                 // problem this sample belongs to
+    const int nb_pts = n_dev ? min(n_dev[b], N) : N;
+    pts += (size_t)b * N;
     const SV A{lds + threadIdx.x}, W{lds + 81 * kLanes + threadIdx.x};
     for (int k = 0; k < 81; ++k) A[k] = 0;
     for (int i = 0; i < 7; ++i) {
         int idx = live ? samples[(size_t)h * 7 + i] : 0;
-        idx = min(max(idx, 0), N - 1);
+        idx = max(min(idx, nb_pts - 1), 0);
         const float4 p = pts[idx];
         const double x0 = p.x, y0 = p.y, x1 = p.z, y1 = p.w;
         const SV r = A.at(i * 9);
@@ -231,6 +247,7 @@ void solve_7pt_kernel(const int32_t* __restrict__ samples, int H, const float4* 
     if (n < 1 || n > 3) n = 0;
     if (!live) return;
     nmodels[h] = n;
+    append_slots(list, nlist, b, h - b * per, per, 3, n);
     for (int k = 0; k < n; ++k) {
         double* F = models + ((size_t)h * 3 + k) * 9;
         double lambda = r[k], mu = 1.;
@@ -593,11 +610,16 @@ __device__ int p3p_lengths(double lengths[4][3], const double* distances, const 
 __global__ __launch_bounds__(kLanes)
 void solve_p3p_kernel(const int32_t* __restrict__ samples, int H, const float* __restrict__ obj,
                       const float2* __restrict__ img, int N, double fx, double fy, double cx, double cy,
-                      double* __restrict__ models, double* __restrict__ rvecs, int32_t* __restrict__ nmodels)
+                      double* __restrict__ models, double* __restrict__ rvecs, int32_t* __restrict__ nmodels,
+                      int per, int32_t* __restrict__ list, int32_t* __restrict__ nlist, const int32_t* __restrict__ n_dev)
 {
     __shared__ double lds[21 * kLanes];
     const int h = blockIdx.x * kLanes + threadIdx.x;
     const bool live = h < H;
+    const int b = live ? h / per : 0;
+    const int nb_pts = n_dev ? min(n_dev[b], N) : N;
+    obj += (size_t)b * N * 3;
+    img += (size_t)b * N;
     const SV scratch{lds + threadIdx.x};
 
     const double ifx = 1. / fx, ify = 1. / fy;
@@ -606,7 +628,7 @@ void solve_p3p_kernel(const int32_t* __restrict__ samples, int H, const float* _
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int idx = live ? samples[(size_t)h * 4 + i] : 0;
-        idx = min(max(idx, 0), N - 1);
+        idx = max(min(idx, nb_pts - 1), 0);
         const float2 uv = img[idx];
         iu[i] = uv.x; iv[i] = uv.y;
         // undistortPoints round trip: (u-cx)*(1/fx) stored as f32, then x*fx+cx
@@ -695,6 +717,7 @@ void solve_p3p_kernel(const int32_t* __restrict__ samples, int H, const float* _
         }
     if (!live) return;
     nmodels[h] = nb > 0 ? 1 : 0;
+    append_slots(list, nlist, b, h - b * per, per, 1, nb > 0 ? 1 : 0);
     if (nb > 0) {
         const int o = order[pos[0]];
 #pragma unroll
@@ -797,16 +820,20 @@ __device__ int solve_poly(const double* coeffs, int deg, double* re, double* im)
 
 __global__ __launch_bounds__(kLanes)
 void solve_5pt_kernel(const int32_t* __restrict__ samples, int H, const double* __restrict__ pts, int N,
-                      double* __restrict__ models, int32_t* __restrict__ nmodels)
+                      double* __restrict__ models, int32_t* __restrict__ nmodels,
+                      int per, int32_t* __restrict__ list, int32_t* __restrict__ nlist, const int32_t* __restrict__ n_dev)
 {
     __shared__ double lds[(81 + 9) * kLanes];
     const int h = blockIdx.x * kLanes + threadIdx.x;
     const bool live = h < H;
+    const int b = live ? h / per : 0;
+    const int nb_pts = n_dev ? min(n_dev[b], N) : N;
+    pts += (size_t)b * N * 4;
     const SV A9{lds + threadIdx.x}, W{lds + 81 * kLanes + threadIdx.x};
     for (int k = 0; k < 81; ++k) A9[k] = 0;
     for (int i = 0; i < 5; ++i) {
         int idx = live ? samples[(size_t)h * 5 + i] : 0;
-        idx = min(max(idx, 0), N - 1);
+        idx = max(min(idx, nb_pts - 1), 0);
         const double x1 = pts[(size_t)idx * 4], y1 = pts[(size_t)idx * 4 + 1];
         const double x2 = pts[(size_t)idx * 4 + 2], y2 = pts[(size_t)idx * 4 + 3];
         const SV r = A9.at(9 * i);
@@ -924,10 +951,43 @@ void solve_5pt_kernel(const int32_t* __restrict__ samples, int H, const double* 
             count++;
         }
     }
-    if (live) nmodels[h] = count;
+    if (live) {
+        nmodels[h] = count;
+        append_slots(list, nlist, b, h - b * per, per, 10, count);
+    }
 }
 
 }  // namespace
+
+// internal launchers shared with the fused batched pipelines in vo_ransac.hip.  H = total samples
+// (all problems), per = samples per problem, N = correspondences per problem (array stride).
+int vo_launch_solve_7pt(const int32_t* samples, int H, int per, const float* pts, int N, const int32_t* n_dev,
+                        double* models, int32_t* nmodels, int32_t* list, int32_t* nlist, hipStream_t s)
+{
+    hipLaunchKernelGGL(solve_7pt_kernel, dim3(vo_ceil_div(H, kLanes)), dim3(kLanes), 0, s, samples, H,
+                       (const float4*)pts, N, models, nmodels, per, list, nlist, n_dev);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}
+
+int vo_launch_solve_5pt(const int32_t* samples, int H, int per, const double* pts, int N, const int32_t* n_dev,
+                        double* models, int32_t* nmodels, int32_t* list, int32_t* nlist, hipStream_t s)
+{
+    hipLaunchKernelGGL(solve_5pt_kernel, dim3(vo_ceil_div(H, kLanes)), dim3(kLanes), 0, s, samples, H, pts, N,
+                       models, nmodels, per, list, nlist, n_dev);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}
+
+int vo_launch_solve_p3p(const int32_t* samples, int H, int per, const float* obj, const float* img, const double* K4,
+                        int N, const int32_t* n_dev, double* models, double* rvecs, int32_t* nmodels, int32_t* list,
+                        int32_t* nlist, hipStream_t s)
+{
+    hipLaunchKernelGGL(solve_p3p_kernel, dim3(vo_ceil_div(H, kLanes)), dim3(kLanes), 0, s, samples, H, obj,
+                       (const float2*)img, N, K4[0], K4[1], K4[2], K4[3], models, rvecs, nmodels, per, list, nlist, n_dev);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}
 
 #define SOLVE_ARG_CHECKS(name)                                                             \
     VO_CHECK_ARG(H >= 0 && N >= 0, VO_EINVAL, name ": negative size");                     \
@@ -940,10 +1000,7 @@ extern "C" int vo_solve_7pt(const int32_t* samples, int H, const float* pts, int
 {
     SOLVE_ARG_CHECKS("vo_solve_7pt");
     VO_CHECK_ARG(pts && ((uintptr_t)pts & 15) == 0, VO_EINVAL, "vo_solve_7pt: pts null or not 16-byte aligned");
-    hipLaunchKernelGGL(solve_7pt_kernel, dim3(vo_ceil_div(H, kLanes)), dim3(kLanes), 0, (hipStream_t)stream,
-                       samples, H, (const float4*)pts, N, models, nmodels);
-    VO_LAUNCH_CHECK();
-    return VO_OK;
+    return vo_launch_solve_7pt(samples, H, H, pts, N, nullptr, models, nmodels, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int vo_solve_5pt(const int32_t* samples, int H, const double* pts, int N, double* models,
@@ -951,10 +1008,7 @@ extern "C" int vo_solve_5pt(const int32_t* samples, int H, const double* pts, in
 {
     SOLVE_ARG_CHECKS("vo_solve_5pt");
     VO_CHECK_ARG(pts != nullptr, VO_EINVAL, "vo_solve_5pt: null pts");
-    hipLaunchKernelGGL(solve_5pt_kernel, dim3(vo_ceil_div(H, kLanes)), dim3(kLanes), 0, (hipStream_t)stream,
-                       samples, H, pts, N, models, nmodels);
-    VO_LAUNCH_CHECK();
-    return VO_OK;
+    return vo_launch_solve_5pt(samples, H, H, pts, N, nullptr, models, nmodels, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int vo_solve_p3p(const int32_t* samples, int H, const float* obj, const float* img,
@@ -964,9 +1018,6 @@ extern "C" int vo_solve_p3p(const int32_t* samples, int H, const float* obj, con
     SOLVE_ARG_CHECKS("vo_solve_p3p");
     VO_CHECK_ARG(obj && img && K4_host && rvecs && ((uintptr_t)img & 7) == 0, VO_EINVAL,
                  "vo_solve_p3p: null/unaligned pointer");
-    hipLaunchKernelGGL(solve_p3p_kernel, dim3(vo_ceil_div(H, kLanes)), dim3(kLanes), 0, (hipStream_t)stream,
-                       samples, H, obj, (const float2*)img, N, K4_host[0], K4_host[1], K4_host[2], K4_host[3],
-                       models, rvecs, nmodels);
-    VO_LAUNCH_CHECK();
-    return VO_OK;
+    return vo_launch_solve_p3p(samples, H, H, obj, img, K4_host, N, nullptr, models, rvecs, nmodels, nullptr, nullptr,
+                               (hipStream_t)stream);
 }

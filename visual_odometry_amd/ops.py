@@ -246,6 +246,53 @@ def argmax_first(counts: torch.Tensor) -> torch.Tensor:
     return result
 
 
+KIND_FUND, KIND_ESS, KIND_PNP = 0, 1, 2
+_SAMPLE_WIDTH = {KIND_FUND: 7, KIND_ESS: 5, KIND_PNP: 4}
+
+
+def ransac_batch(kind: int, samples: torch.Tensor, pts: torch.Tensor, threshold: float, confidence: float,
+                 max_iters: int, img: Optional[torch.Tensor] = None, K=None, n_dev: Optional[torch.Tensor] = None,
+                 workspace: Optional[torch.Tensor] = None):
+    """Fused solve -> score -> replay -> mask for a batch of same-shape problems, no host sync.
+
+    samples (B,H,m) i32; pts (B,N,4) f32 [F] | (B,N,4) f64 [E] | (B,N,3) f32 object points [PnP, with
+    img (B,N,2) f32 and K].  -> result (B,4) i32, best_model (B,9|12) f64, best_rvec (B,3) f64 | None,
+    mask (B,N) u8."""
+    _lib.require_device()
+    lib = _lib.load()
+    m = _SAMPLE_WIDTH[kind]
+    samples = _dev(samples, torch.int32, "samples")
+    if samples.ndim != 3 or samples.shape[2] != m:
+        raise _lib.VoError(f"samples must be (B,H,{m})")
+    B, H = samples.shape[0], samples.shape[1]
+    pts = _dev(pts, torch.float64 if kind == KIND_ESS else torch.float32, "pts")
+    last = 3 if kind == KIND_PNP else 4
+    if pts.ndim != 3 or pts.shape[0] != B or pts.shape[2] != last:
+        raise _lib.VoError(f"pts must be (B,N,{last})")
+    N = pts.shape[1]
+    img_p = k4 = None
+    if kind == KIND_PNP:
+        img = _dev(img, torch.float32, "img")
+        if tuple(img.shape) != (B, N, 2):
+            raise _lib.VoError("img must be (B,N,2)")
+        img_p, k4 = _ptr(img), _K4(K)
+    nd = None if n_dev is None else _dev(n_dev, torch.int32, "n_dev")
+    dev = samples.device
+    result = torch.empty((B, 4), dtype=torch.int32, device=dev)
+    mw = 12 if kind == KIND_PNP else 9
+    best = torch.empty((B, mw), dtype=torch.float64, device=dev)
+    rvec = torch.empty((B, 3), dtype=torch.float64, device=dev) if kind == KIND_PNP else None
+    mask = torch.empty((B, N), dtype=torch.uint8, device=dev)
+    need = lib.vo_ransac_workspace_bytes(kind, H, B)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty((need,), dtype=torch.uint8, device=dev)
+    _lib.check(lib.vo_ransac_batch(kind, _ptr(samples), H, _ptr(pts), img_p, k4, N, _ptr(nd), B, thr2_of(threshold),
+                                   float(confidence), int(max_iters), _ptr(result), _ptr(best), _ptr(rvec), _ptr(mask),
+                                   _ptr(workspace), workspace.numel() * workspace.element_size(), _stream()),
+               "vo_ransac_batch")
+    return result, best, rvec, mask
+
+
 # ------------------------------------------------------------------------------- host helpers
 def gen_subsets(n_points: int, model_points: int, max_iters: int, pts4_host: Optional[np.ndarray] = None) -> np.ndarray:
     """cv::RNG((uint64)-1) + getSubset sample stream (host only). (n_generated, model_points) i32."""
