@@ -130,7 +130,7 @@ def main():
     dev = torch.device("cuda", local)
     _lib.require_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:      # under torchrun, also with one rank
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 

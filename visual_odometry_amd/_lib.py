@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvo_hip.so")
+# VO_HIP_LIB: load another build of the same library (kernel ablation experiments only)
+LIB_PATH = os.environ.get("VO_HIP_LIB") or os.path.join(_HERE, "libvo_hip.so")
 
 VO_OK = 0
 VO_DESC_BAD_VALUE = 1

@@ -19,16 +19,38 @@
 // train index, which is OpenCV's tie rule (strict '<' insertion while scanning upwards).
 #include "vo_common.h"
 #include <limits.h>
+#include <stdlib.h>
+
+// shape of the sweep kernel (defaults chosen by measurement, scripts/knn_variants.sh)
+#ifndef VO_KNN_SETS
+#define VO_KNN_SETS 2        /* 32-query sets per wave */
+#endif
+#ifndef VO_KNN_WAVES
+#define VO_KNN_WAVES 8       /* waves per workgroup */
+#endif
+#ifndef VO_KNN_TILES
+#define VO_KNN_TILES 4       /* 32-row train tiles per LDS stage */
+#endif
+#ifndef VO_KNN_MINW
+#define VO_KNN_MINW 2        /* waves per SIMD the register allocation must allow */
+#endif
+#ifndef VO_SCHED
+#define VO_SCHED 0
+#endif
+#ifndef VO_ABLATE
+#define VO_ABLATE 0      /* 1, 2: timing experiments only (scripts/knn_ablate.sh), results are wrong */
+#endif
 
 namespace {
 
 constexpr int kDim = VO_DESC_DIM;
 constexpr int kTileRows = 32;
-constexpr int kChunkTiles = 4;
+constexpr int kChunkTiles = VO_KNN_TILES;
 constexpr int kChunkRows = kTileRows * kChunkTiles;          // 128 train rows per LDS stage
 constexpr int kSegTiles = 16;                                 // tile index bits in the key
-constexpr int kWaveQ = 64;                                    // query rows per wave
-constexpr int kWgWaves = 4;
+constexpr int kSets = VO_KNN_SETS;                                      // 32-query sets per wave
+constexpr int kWaveQ = 32 * kSets;                            // query rows per wave
+constexpr int kWgWaves = VO_KNN_WAVES;
 constexpr int kWgQ = kWaveQ * kWgWaves;                       // 256 query rows per workgroup
 constexpr int kWgThreads = 64 * kWgWaves;
 constexpr int kBufBytes = kChunkRows * kDim + kChunkRows * 4; // rows + their c[] words
@@ -66,23 +88,44 @@ __device__ __forceinline__ Top2 merge2(const Top2& a, const Top2& b)
     return o;
 }
 
-// v_med3_i32 has no clang builtin; one VALU op, inputs/outputs are ordinary VGPRs
+// v_med3_i32 as inline asm: besides the missing builtin, the asm statements keep hipcc's scheduler
+// from hoisting every MFMA and LDS read of the unrolled chunk to the top (which spills); the
+// source order below is the intended issue order
 __device__ __forceinline__ int med3i(int a, int b, int c)
 {
     int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    asm volatile("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 
-__global__ __launch_bounds__(kWgThreads, 2)
+typedef __attribute__((address_space(3))) void lds_void;
+
+// One 1 KiB LDS-DMA piece = 8 train rows: lane L fills the 16-byte slot (row L>>3, slot L&7) of
+// the piece.  The destination of an LDS-DMA is lane-linear, so the XOR swizzle of the image goes
+// on the SOURCE: slot pc of row R holds the row's 16-byte column pc ^ ((R>>1)&7).
+__device__ __forceinline__ void stage_piece(const int8_t* __restrict__ t, char* lds_piece, int row_in_chunk0,
+                                            int grow0, int row_end, int lane)
+{
+    const int r = lane >> 3, pc = lane & 7;
+    const int R = row_in_chunk0 + r, gr = grow0 + r;
+    if (gr < row_end) {
+        const int ck = pc ^ ((R >> 1) & 7);
+        __builtin_amdgcn_global_load_lds((const void*)(t + (size_t)gr * kDim + ck * 16), (lds_void*)lds_piece, 16, 0, 0);
+    } else {
+        const v4i z = {0, 0, 0, 0};                       // rows past the split: all-zero => dot 0
+        *(v4i*)(lds_piece + lane * 16) = z;
+    }
+}
+
+__global__ __launch_bounds__(kWgThreads, VO_KNN_MINW)
 void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict__ t,
                          const int32_t* __restrict__ tnorm, int nq, int nt,
                          int rows_per_split, int nsplit, int4* __restrict__ partial,
                          const int32_t* __restrict__ qnorm, int32_t* __restrict__ idx,
                          int32_t* __restrict__ d2)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // the ONLY LDS object (2 buffers)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qblock = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
     q += (size_t)b * nq * kDim;
@@ -96,61 +139,51 @@ void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict_
     // ---- query rows -> MFMA B fragments (lane: column = query lane&31, k-slice by lane>>5)
     const int qrow = lane & 31, h = lane >> 5;
     const int qbase = qblock * kWgQ + wave * kWaveQ;
-    v4i qb[2][4];
+    v4i qb[kSets][4];
 #pragma unroll
-    for (int set = 0; set < 2; ++set) {
+    for (int set = 0; set < kSets; ++set) {
         const int qi = qbase + set * 32 + qrow;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            // unconditional load of a clamped row, then select: no branch around the load
             const v4i v = *(const v4i*)(q + (size_t)min(qi, nq - 1) * kDim + 32 * s + 16 * h);
             const v4i z = {0, 0, 0, 0};
             qb[set][s] = qi < nq ? v : z;
         }
     }
 
-    // ---- staging registers (global -> regs early, regs -> LDS after the compute phase)
-    v4i st[4];
-    int stc = INT_MIN;
-    auto stage_load = [&](int chunk) {
+    // ---- staging: every wave DMAs 8 pieces (64 rows) of a chunk; thread tid forms the key
+    // constant of row tid
+    auto stage_rows = [&](int chunk, int buf) {
+        char* base = smem + buf * kBufBytes;
         const int rbase = row0 + chunk * kChunkRows;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + kWgThreads * i, r = idx >> 3, ck = idx & 7, gr = rbase + r;
-            const v4i v = *(const v4i*)(t + (size_t)min(gr, row_end - 1) * kDim + ck * 16);
-            const v4i z = {0, 0, 0, 0};
-            st[i] = gr < row_end ? v : z;          // rows past the split must be all-zero
-        }
-        if (tid < kChunkRows) {
-            const int gr = rbase + tid;
-            const int tn = tnorm[min(gr, row_end - 1)];
-            const int tile16 = ((gr - row0) >> 5) & (kSegTiles - 1);
-            const int i = tid & 31, slot = (i & 3) | ((i >> 3) << 2);
-            stc = gr < row_end ? (-tn) * 256 + ((15 - tile16) << 4) + (15 - slot) : INT_MIN;
+        for (int j = 0; j < kChunkRows / 8 / kWgWaves; ++j) {
+            const int piece = wave * (kChunkRows / 8 / kWgWaves) + j;
+            stage_piece(t, base + piece * 1024, piece * 8, rbase + piece * 8, row_end, lane);
         }
     };
-    auto stage_store = [&](int buf) {
-        char* base = smem + buf * kBufBytes;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + kWgThreads * i, r = idx >> 3, ck = idx & 7;
-            *(v4i*)(base + r * kDim + ((ck ^ ((r >> 1) & 7)) << 4)) = st[i];
-        }
-        if (tid < kChunkRows) ((int*)(base + kChunkRows * kDim))[tid] = stc;
+    auto stage_c = [&](int chunk, int buf) {
+        if (tid >= kChunkRows) return;
+        const int gr = row0 + chunk * kChunkRows + tid;
+        const int tn = tnorm[min(gr, row_end - 1)];
+        const int tile16 = ((gr - row0) >> 5) & (kSegTiles - 1);
+        const int i = tid & 31, slot = (i & 3) | ((i >> 3) << 2);
+        const int c = gr < row_end ? (-tn) * 256 + ((15 - tile16) << 4) + (15 - slot) : INT_MIN;
+        ((int*)(smem + buf * kBufBytes + kChunkRows * kDim))[tid] = c;
     };
 
-    Top2 run[2];
+    Top2 run[kSets];
 #pragma unroll
-    for (int set = 0; set < 2; ++set) { run[set].k1 = run[set].k2 = INT_MIN; run[set].j1 = run[set].j2 = -1; }
-    int m1[2][2], m2[2][2];          // [set][chain] packed running top-2 of the current segment
+    for (int set = 0; set < kSets; ++set) { run[set].k1 = run[set].k2 = INT_MIN; run[set].j1 = run[set].j2 = -1; }
+    int m1[kSets][2], m2[kSets][2];  // [set][chain] packed running top-2 of the current segment
 #pragma unroll
-    for (int set = 0; set < 2; ++set)
+    for (int set = 0; set < kSets; ++set)
 #pragma unroll
         for (int c = 0; c < 2; ++c) m1[set][c] = m2[set][c] = INT_MIN;
 
     auto fold = [&](int seg_row_base) {
 #pragma unroll
-        for (int set = 0; set < 2; ++set) {
+        for (int set = 0; set < kSets; ++set) {
             const int a1 = m1[set][0], a2 = m2[set][0], b1 = m1[set][1], b2 = m2[set][1];
             const int n1 = max(a1, b1);
             const int n2 = max3i(min(a1, b1), a2, b2);
@@ -167,55 +200,76 @@ void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict_
         }
     };
 
+    // top-2 update of one 32x32 tile of dot products: 3 VALU ops per element
+    auto epilogue = [&](const v16i& acc, const v4i* cv, int set) {
+#if VO_ABLATE == 1          /* experiment: no top-2 epilogue */
+        asm volatile("" :: "v"(acc));
+        m1[set][0] = max(m1[set][0], cv[0][0] + cv[1][1] + cv[2][2] + cv[3][3]);
+#else
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = (acc[r] << 9) + cv[r >> 2][r & 3];
+            const int c = r & 1;
+            m2[set][c] = med3i(m1[set][c], m2[set][c], p);
+            m1[set][c] = max(m1[set][c], p);
+        }
+#endif
+    };
+
     if (nchunks > 0) {
-        stage_load(0);
-        stage_store(0);
+        stage_rows(0, 0);
+        stage_c(0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int buf = chunk & 1;
-        if (chunk + 1 < nchunks) stage_load(chunk + 1);
+        if (VO_ABLATE != 4 && VO_ABLATE != 5 && chunk + 1 < nchunks) stage_rows(chunk + 1, buf ^ 1);   // DMA runs under the sweep below
 
         const char* base = smem + buf * kBufBytes;
         const int* cbase = (const int*)(base + kChunkRows * kDim);
+        const char* fbase = base + qrow * kDim;
+        int foff[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) foff[s] = ((2 * s + h) ^ ((qrow >> 1) & 7)) << 4;
+
+        // no software pipelining: 4 waves per SIMD (two 8-wave workgroups per CU) cover the MFMA
+        // chain latency and the LDS reads of one wave with the top-2 VALU work of the others
 #pragma unroll
         for (int tile = 0; tile < kChunkTiles; ++tile) {
-            const char* tb = base + tile * kTileRows * kDim;
-            v4i va[4];
+            v4i va[4], cv[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                va[s] = *(const v4i*)(tb + qrow * kDim + (((2 * s + h) ^ ((qrow >> 1) & 7)) << 4));
-            v4i cv[4];
+            for (int s = 0; s < 4; ++s) va[s] = *(const v4i*)(fbase + (VO_ABLATE == 3 ? 0 : tile) * kTileRows * kDim + foff[s]);
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                cv[g] = *(const v4i*)(cbase + tile * kTileRows + 8 * g + 4 * h);
-
+            for (int g = 0; g < 4; ++g) cv[g] = *(const v4i*)(cbase + (VO_ABLATE == 3 ? 0 : tile) * kTileRows + 8 * g + 4 * h);
 #pragma unroll
-            for (int set = 0; set < 2; ++set) {
+            for (int set = 0; set < kSets; ++set) {
                 v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#if VO_ABLATE == 2          /* experiment: no MFMA */
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { acc[4 * s] = va[s][0] ^ qb[set][s][0]; acc[4 * s + 1] = va[s][1]; acc[4 * s + 2] = va[s][2]; acc[4 * s + 3] = va[s][3]; }
+#else
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
                     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(va[s], qb[set][s], acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int p = (acc[r] << 9) + cv[r >> 2][r & 3];
-                    const int c = r & 1;
-                    m2[set][c] = med3i(m1[set][c], m2[set][c], p);
-                    m1[set][c] = max(m1[set][c], p);
-                }
+#endif
+                epilogue(acc, cv, set);
             }
         }
 
-        if (chunk + 1 < nchunks) stage_store(buf ^ 1);
+        if (VO_ABLATE != 4 && VO_ABLATE != 5 && chunk + 1 < nchunks) stage_c(chunk + 1, buf ^ 1);
         if (((chunk + 1) & (kSegTiles / kChunkTiles - 1)) == 0 || chunk + 1 == nchunks)
             fold(row0 + (chunk / (kSegTiles / kChunkTiles)) * (kSegTiles * kTileRows));
-        __syncthreads();
+        if (VO_ABLATE != 5) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
 
     // ---- the two lane halves hold the same query over interleaved train rows: merge
 #pragma unroll
-    for (int set = 0; set < 2; ++set) {
+    for (int set = 0; set < kSets; ++set) {
         Top2 o;
         o.k1 = __shfl_xor(run[set].k1, 32); o.j1 = __shfl_xor(run[set].j1, 32);
         o.k2 = __shfl_xor(run[set].k2, 32); o.j2 = __shfl_xor(run[set].j2, 32);
@@ -329,7 +383,8 @@ KnnPlan knn_plan(int nq, int nt, int batch)
 {
     KnnPlan p;
     p.nqb = vo_ceil_div(nq > 0 ? nq : 1, kWgQ);
-    const long want = 2L * cu_count();                       // two workgroups per CU
+    static const long per_cu = getenv("VO_KNN_WG_PER_CU") ? atol(getenv("VO_KNN_WG_PER_CU")) : 2;   // tuning knob
+    const long want = per_cu * cu_count();                   // two 8-wave workgroups per CU
     long ns = (want + (long)p.nqb * batch - 1) / ((long)p.nqb * batch);
     const int max_ns = vo_ceil_div(nt > 0 ? nt : 1, kSegTiles * kTileRows);
     if (ns > max_ns) ns = max_ns;
@@ -370,6 +425,13 @@ extern "C" int vo_knn2_l2_i8(const int8_t* q, const int32_t* qnorm, int nq,
                  "vo_knn2_l2_i8: workspace of %zu bytes (16-byte aligned) required, got %zu", need, workspace_bytes);
     VO_CHECK_ARG(p.nsplit <= 65535, VO_ESIZE, "vo_knn2_l2_i8: too many train splits");
     int4* partial = (int4*)workspace;
+    if (kLdsBytes > 65536) {                         // large dynamic LDS needs an opt-in
+        static bool lds_attr_set = false;
+        if (!lds_attr_set) {
+            VO_HIP_TRY(hipFuncSetAttribute((const void*)knn2_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+            lds_attr_set = true;
+        }
+    }
     dim3 grid(p.nqb, p.nsplit, batch);
     vo_prof_begin(VO_STAGE_KNN, 0, s);
     hipLaunchKernelGGL(knn2_partial_kernel, grid, dim3(kWgThreads), kLdsBytes, s, q, t, tnorm, nq, nt,
