@@ -195,20 +195,31 @@ def main():
     knn_ops = 2.0 * NQ * NT * 128 * args.pairs
     knn_tops = knn_ops / avg["knn2"] / 1e12
 
+    # physical HBM traffic per launch: PMC counters need their own rocprofv3 passes, so they are
+    # measured separately on the same command (scripts/gpu_pmc.sh) and kept under profiles/
+    traffic = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as fh:
+            tj = json.load(fh)
+        if args.pairs == 16:
+            traffic = {k: v["hbm_bytes_per_launch"] for k, v in tj.items() if isinstance(v, dict)}
+    except (OSError, ValueError, KeyError):
+        pass
     dominant = max(tot, key=tot.get)
     roof = {
         "score_fund": {"kernel": "score_fund_kernel", "bound": "hbm", "achieved": sf_gbs, "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": sf_gbs / HBM_PEAK_GBS, "traffic": None,
+                       "unit": "GB/s", "frac": sf_gbs / HBM_PEAK_GBS, "traffic": traffic.get("score_fund_kernel"),
+                       "traffic_note": "HBM bytes per launch from rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes: profiles/r1_traffic.json",
                        "note": "effective streaming bytes (16 B per model x correspondence); the tiled kernel "
                                "re-uses points from LDS so physical HBM traffic is far lower and the real limiter "
                                "is the f64 VALU",
                        "f64_tflops": n_models_f * NPTS * 49 / avg["score_fund"] / 1e12, "f64_peak_tflops": FP64_PEAK_TFLOPS,
                        "units_per_launch": f"{n_models_f} models x {NPTS} correspondences ({B} frame pairs)"},
         "score_pnp": {"kernel": "score_pnp_kernel", "bound": "hbm", "achieved": sp_gbs, "peak": HBM_PEAK_GBS,
-                      "unit": "GB/s", "frac": sp_gbs / HBM_PEAK_GBS, "traffic": None,
+                      "unit": "GB/s", "frac": sp_gbs / HBM_PEAK_GBS, "traffic": traffic.get("score_pnp_kernel"),
                       "units_per_launch": f"{n_models_p} models x {NPTS} correspondences ({B} frame pairs)"},
         "knn2": {"kernel": "knn2_partial_kernel", "bound": "mfma", "achieved": knn_tops, "peak": i8_peak_tops,
-                 "unit": "TOP/s", "frac": knn_tops / i8_peak_tops, "traffic": None,
+                 "unit": "TOP/s", "frac": knn_tops / i8_peak_tops, "traffic": traffic.get("knn2_partial_kernel"),
                  "note": f"int8 dense peak = {cus} CU x {I8_OPS_PER_CLK_CU} ops/clk x {clock_ghz} GHz",
                  "units_per_launch": f"{B} frame pairs of {NQ} x {NT} descriptors"},
     }
