@@ -37,6 +37,7 @@ H = 4096                     # RANSAC iterations (sample sets) per problem
 NPTS = 4096                  # correspondences per RANSAC problem (~ratio-test survivors of 8192)
 F_THR, F_CONF = 0.1, 0.9999  # reference src/params.py:24-27
 P_THR, P_CONF = 1.0, 0.9999  # reference src/params.py:72-75
+P_FIRST_BLOCK = 256          # PnP iterations evaluated before the first early-termination check
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E
 I8_OPS_PER_CLK_CU = 8192     # 4 SIMD x 2048 int8 ops/clk (v_mfma_i32_32x32x32_i8: 65536 ops / 32 clk)
@@ -80,7 +81,8 @@ def step(ps: PairSet):
     idx, d2 = ops.knn2(qi8.reshape(B, NQ, 128), qn.reshape(B, NQ), ti8.reshape(B, NT, 128), tn.reshape(B, NT), ps.ws)
     keep, nkeep = ops.ratio_test(d2.reshape(B * NQ, 2), 0.8)
     f = ops.ransac_batch(ops.KIND_FUND, ps.f_sub, ps.f_pts, F_THR, F_CONF, H, workspace=ps.ws)
-    p = ops.ransac_batch(ops.KIND_PNP, ps.p_sub, ps.p_obj, P_THR, P_CONF, H, img=ps.p_img, K=synth.K_MALAGA, workspace=ps.ws)
+    p = ops.ransac_batch(ops.KIND_PNP, ps.p_sub, ps.p_obj, P_THR, P_CONF, H, img=ps.p_img, K=synth.K_MALAGA, workspace=ps.ws,
+                         first_block=P_FIRST_BLOCK)
     return idx, keep, nkeep, f, p
 
 
@@ -141,7 +143,7 @@ def main():
     torch.cuda.synchronize()
     # HIP events around single launches inside the entry points (the scoring kernels of both RANSAC
     # runs and the kNN sweep kernel), recorded on the stream those kernels run on
-    _lib.check(lib.vo_profile_enable((1 << 1) | (1 << 4), 3 * args.steps + 8), "vo_profile_enable")
+    _lib.check(lib.vo_profile_enable((1 << 1) | (1 << 4), 16 * args.steps + 8), "vo_profile_enable")
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -158,27 +160,51 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    cap = 3 * args.steps + 8
+    cap = 16 * args.steps + 8
     tags = np.zeros(cap, np.int32); ms = np.zeros(cap, np.float32)
     nrec = lib.vo_profile_collect(tags.ctypes.data, ms.ctypes.data, cap)
     _lib.check(nrec, "vo_profile_collect")
     lib.vo_profile_enable(0, 0)
-    # records arrive in launch order: knn (tag 0), score F (tag 0), score PnP (tag 2) per step
-    names = ["knn2", "score_fund", "score_pnp"]
-    dur = {n: [] for n in names}
+    # tag 0x1000 = kNN sweep kernel; otherwise kind | iteration-block << 8 of a scoring launch.  The
+    # scoring time of one RANSAC run is the sum over its iteration blocks (later blocks return at
+    # once for problems that already terminated).
+    tot = {"knn2": 0.0, "score_fund": 0.0, "score_pnp": 0.0}
     for i in range(nrec):
-        dur[names[i % 3]].append(float(ms[i]) * 1e-3)
-    avg = {k: float(np.mean(v)) for k, v in dur.items()}
-    tot = {k: float(np.sum(v)) for k, v in dur.items()}
-    # how many models the scoring launches really evaluated (samples with no real root / no P3P
-    # solution have no model; the fused path skips their slots), counted outside the timed region
+        name = "knn2" if tags[i] == 0x1000 else ("score_fund" if (tags[i] & 0xFF) == 0 else "score_pnp")
+        tot[name] += float(ms[i]) * 1e-3
+    avg = {k: v / args.steps for k, v in tot.items()}
+
+    # how many models the scoring launches really evaluated, counted outside the timed region:
+    # samples with no real root / no P3P solution have no model, and iteration blocks that start at
+    # or after the point where OpenCV's loop ends are skipped (block k ran iff h0_k <= best_iter or
+    # h0_k < final niters)
     B = args.pairs
-    n_models_f = 0
-    n_models_p = 0
-    for b in range(B):
-        n_models_f += int(ops.solve_7pt(ps.f_sub[b], ps.f_pts[b])[1].sum().item())
-        n_models_p += int(ops.solve_p3p(ps.p_sub[b], ps.p_obj[b], ps.p_img[b], synth.K_MALAGA)[2].sum().item())
-    good_f = int((res[3][0][:, 2] > 0).sum().item()); good_p = int((res[4][0][:, 2] > 0).sum().item())
+
+    def blocks(first):
+        out, h0, stage = [], 0, 0
+        while h0 < H:
+            h1 = H
+            if 0 < first < H:
+                h1 = first if stage == 0 else min(h0 * 5, H)
+            if H - h1 < h1 // 4:
+                h1 = H
+            out.append((h0, h1)); h0 = h1; stage += 1
+        return out
+
+    def scored(nm, result, first):
+        n = 0
+        for b in range(B):
+            best_iter, niters = int(result[b, 0]), int(result[b, 3])
+            for h0, h1 in blocks(first):
+                if h0 == 0 or h0 <= best_iter or h0 < niters:
+                    n += int(nm[b][h0:h1].sum())
+        return n
+
+    res_f, res_p = res[3][0].cpu().numpy(), res[4][0].cpu().numpy()
+    nm_f = [ops.solve_7pt(ps.f_sub[b], ps.f_pts[b])[1].cpu().numpy() for b in range(B)]
+    nm_p = [ops.solve_p3p(ps.p_sub[b], ps.p_obj[b], ps.p_img[b], synth.K_MALAGA)[2].cpu().numpy() for b in range(B)]
+    n_models_f, n_models_p = scored(nm_f, res_f, 0), scored(nm_p, res_p, P_FIRST_BLOCK)
+    good_f = int((res_f[:, 2] > 0).sum()); good_p = int((res_p[:, 2] > 0).sum())
 
     prop = torch.cuda.get_device_properties(dev)
     cus = prop.multi_processor_count
@@ -237,7 +263,8 @@ def main():
                            "value": n_models_f * NPTS / avg["score_fund"],
                            "unit": "evals/s per GPU inside the F scoring kernel (models that exist x correspondences)",
                            "pnp_value": n_models_p * NPTS / avg["score_pnp"],
-                           "models_per_pair": {"fund": n_models_f / B, "pnp": n_models_p / B},
+                           "models_scored_per_pair": {"fund": n_models_f / B, "pnp": n_models_p / B},
+                           "final_niters": {"fund": [int(v) for v in res_f[:, 3]], "pnp": [int(v) for v in res_p[:, 3]]},
                            "pairs_with_a_model": {"fund": good_f, "pnp": good_p},
                            "whole_job_evals_per_s": evals_per_step * world * args.steps / dt},
         "kernel_time_share": {k: v / dt for k, v in tot.items()},

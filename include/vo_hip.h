@@ -153,13 +153,18 @@ int vo_ransac_replay(const int32_t* counts, const int32_t* nmodels, int n_iters,
  * result   batch x 4 int32: best iteration (-1 none), best model, maxGood, final niters
  * best_model batch x 9 (kinds 0, 1) or batch x 12 ([R|t], kind 2) f64; best_rvec batch x 3 f64 (kind 2,
  *          may be NULL); mask batch x N uint8.  Scoring skips the empty model slots of samples with
- *          fewer solutions than the maximum. */
+ *          fewer solutions than the maximum.
+ * first_block  0: all H iterations are solved and scored in one go.  > 0: iterations run in blocks
+ *          ([0, first_block), then blocks four times as long as everything before); after each block
+ *          the replay knows which problems OpenCV's adaptive loop would already have left (niters
+ *          <= iterations done) and their remaining iterations are skipped -- same result, less work
+ *          when inliers are plentiful, a few more launches when they are not. */
 size_t vo_ransac_workspace_bytes(int kind, int H, int batch);
 int vo_ransac_batch(int kind, const int32_t* samples, int H, const void* pts, const float* img,
                     const double* K4_host, int N, const int32_t* n_dev, int batch, float thr2,
-                    double confidence, int max_iters, int32_t* result, double* best_model,
-                    double* best_rvec, uint8_t* mask, void* workspace, size_t workspace_bytes,
-                    void* stream);
+                    double confidence, int max_iters, int first_block, int32_t* result,
+                    double* best_model, double* best_rvec, uint8_t* mask, void* workspace,
+                    size_t workspace_bytes, void* stream);
 
 /* result (2 x int32): largest count and the lowest index holding it (pure argmax mode). */
 int vo_argmax_first(const int32_t* counts, int n, int32_t* result, void* stream);
@@ -184,7 +189,8 @@ int vo_host_epnp(const double* obj_host, const double* img_host, int n, const do
 /* ------------------------------------------------------------------------------------
  * Measurement aid (no counterpart in the reference): HIP-event timing of single launches inside
  * the entry points above, on the stream they run on.  stage_mask bits: 0 solve, 1 score, 2 replay,
- * 3 mask (inside vo_ransac_batch; tag = kind), 4 the kNN sweep kernel (inside vo_knn2_l2_i8).
+ * 3 mask (inside vo_ransac_batch; tag = kind | iteration-block index << 8), 4 the kNN sweep kernel
+ * (inside vo_knn2_l2_i8; tag 0x1000).
  * vo_profile_enable(0, 0) switches it off.  vo_profile_collect waits for the recorded events and
  * returns how many (tag, milliseconds) records it wrote; it resets the record list.
  * ---------------------------------------------------------------------------------- */

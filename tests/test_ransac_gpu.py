@@ -251,8 +251,10 @@ def test_replay_long_and_batched(oracle_mod, dev):
         assert tuple(int(v) for v in res) == oracle_mod.ransac_replay(cnts[b], nm[b], 3000, 7, 0.9999, n_it), b
 
 
-@pytest.mark.parametrize("B,H,N", [(3, 512, 700), (1, 100, 2000), (6, 1100, 333)])
-def test_ransac_batch_fund_and_pnp(det_math, dev, B, H, N):
+@pytest.mark.parametrize("B,H,N,first_block", [(3, 512, 700, 0), (1, 100, 2000, 0), (6, 1100, 333, 0),
+                                                (3, 512, 700, 64), (6, 1100, 333, 37), (2, 2000, 500, 16)])
+def test_ransac_batch_fund_and_pnp(det_math, dev, B, H, N, first_block):
+    """first_block > 0: iterations run in blocks with early termination -- results must not change."""
     o = det_math
     f_pts, f_sub, p_obj, p_img, p_sub = [], [], [], [], []
     for b in range(B):
@@ -262,9 +264,10 @@ def test_ransac_batch_fund_and_pnp(det_math, dev, B, H, N):
         ps = synth.pnp_scene(N, seed=80 + b)
         p_obj.append(ps["obj"]); p_img.append(ps["img"]); p_sub.append(ops.gen_subsets(N, 4, H))
     K = synth.K_MALAGA
-    res, best, _, mask = ops.ransac_batch(ops.KIND_FUND, _d(np.stack(f_sub), dev), _d(np.stack(f_pts), dev), 1.0, 0.999, H)
+    res, best, _, mask = ops.ransac_batch(ops.KIND_FUND, _d(np.stack(f_sub), dev), _d(np.stack(f_pts), dev), 1.0, 0.999, H,
+                                          first_block=first_block)
     resp, bestp, rvp, maskp = ops.ransac_batch(ops.KIND_PNP, _d(np.stack(p_sub), dev), _d(np.stack(p_obj), dev), 2.0, 0.999, H,
-                                               img=_d(np.stack(p_img), dev), K=K)
+                                               img=_d(np.stack(p_img), dev), K=K, first_block=first_block)
     res, best, mask = res.cpu().numpy(), best.cpu().numpy(), mask.cpu().numpy()
     resp, bestp, rvp, maskp = resp.cpu().numpy(), bestp.cpu().numpy(), rvp.cpu().numpy(), maskp.cpu().numpy()
     for b in range(B):
@@ -304,7 +307,7 @@ def test_ransac_batch_ess_and_n_dev(det_math, dev):
         subs.append(s)
     thr = 1.0 / ((fx + fy) / 2)
     res, best, _, mask = ops.ransac_batch(ops.KIND_ESS, _d(np.stack(subs), dev), _d(np.stack(x4s), dev), thr, 0.999, H,
-                                          n_dev=_d(np.array(nvalid, np.int32), dev))
+                                          n_dev=_d(np.array(nvalid, np.int32), dev), first_block=20)
     res, best, mask = res.cpu().numpy(), best.cpu().numpy(), mask.cpu().numpy()
     for b in range(B):
         n = nvalid[b]

@@ -36,20 +36,22 @@ static inline int vo_ceil_div(int a, int b) { return (a + b - 1) / b; }
 enum { VO_KIND_FUND = 0, VO_KIND_ESS = 1, VO_KIND_PNP = 2 };
 int vo_launch_init_counts(const uint8_t* valid, const int32_t* nmodels, int slots_per_sample, long total,
                           int32_t* counts, hipStream_t s);
-int vo_launch_score(int kind, const double* models, const uint8_t* valid, const int32_t* list, const int32_t* nlist,
-                    int H, const void* pts, const float* img, const int32_t* n_dev, int N, int batch,
-                    const double* K4, float thr2, int32_t* counts, hipStream_t s);
+int vo_launch_score(int kind, const double* models, const uint8_t* valid, const int32_t* list, const int32_t* nstart,
+                    const int32_t* nlist, int H, const void* pts, const float* img, const int32_t* n_dev, int N, int batch,
+                    const double* K4, float thr2, int32_t* counts, int max_slots, hipStream_t s);
 int vo_launch_mask_best(int kind, const double* models, int slots_per_problem, int slots_per_sample,
                         const double* aux, int aux_w, double* best_aux, const int32_t* result, const void* pts,
                         const float* img, const int32_t* n_dev, int N, int batch, const double* K4, float thr2,
                         uint8_t* mask, double* best_model, hipStream_t s);
 int vo_launch_solve_7pt(const int32_t* samples, int H, int per, const float* pts, int N, const int32_t* n_dev,
-                        double* models, int32_t* nmodels, int32_t* list, int32_t* nlist, hipStream_t s);
+                        double* models, int32_t* nmodels, int32_t* list, int32_t* nlist, int h0, int hlen,
+                        const int32_t* prev, hipStream_t s);
 int vo_launch_solve_5pt(const int32_t* samples, int H, int per, const double* pts, int N, const int32_t* n_dev,
-                        double* models, int32_t* nmodels, int32_t* list, int32_t* nlist, hipStream_t s);
+                        double* models, int32_t* nmodels, int32_t* list, int32_t* nlist, int h0, int hlen,
+                        const int32_t* prev, hipStream_t s);
 int vo_launch_solve_p3p(const int32_t* samples, int H, int per, const float* obj, const float* img, const double* K4,
                         int N, const int32_t* n_dev, double* models, double* rvecs, int32_t* nmodels, int32_t* list,
-                        int32_t* nlist, hipStream_t s);
+                        int32_t* nlist, int h0, int hlen, const int32_t* prev, hipStream_t s);
 int vo_launch_replay(const int32_t* counts, const int32_t* nmodels, int n_iters, int max_models, int n_points,
                      const int32_t* n_dev, int model_points, double confidence, int max_iters, int batch,
                      int32_t* result, hipStream_t s);

@@ -433,7 +433,7 @@ extern "C" int vo_knn2_l2_i8(const int8_t* q, const int32_t* qnorm, int nq,
         }
     }
     dim3 grid(p.nqb, p.nsplit, batch);
-    vo_prof_begin(VO_STAGE_KNN, 0, s);
+    vo_prof_begin(VO_STAGE_KNN, 0x1000, s);
     hipLaunchKernelGGL(knn2_partial_kernel, grid, dim3(kWgThreads), kLdsBytes, s, q, t, tnorm, nq, nt,
                        p.rows_per_split, p.nsplit, partial, qnorm, idx, d2);
     vo_prof_end(VO_STAGE_KNN, s);

@@ -193,8 +193,8 @@ int vo_launch_replay(const int32_t* counts, const int32_t* nmodels, int n_iters,
 // ---- fused batched pipelines: solve -> score -> replay -> mask for `batch` problems of one shape --
 namespace {
 struct RansacWs {
-    double* models; double* aux; int32_t* nmodels; int32_t* counts; int32_t* list; int32_t* nlist;
-    size_t bytes;
+    double* models; double* aux; int32_t* nmodels; int32_t* counts; int32_t* list; int32_t* nlist; int32_t* nstart;
+    size_t zero_from, zero_bytes, bytes;     // [zero_from, zero_from + zero_bytes) is cleared per call
 };
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 RansacWs carve(void* base, int width, int mw, int aux_w, int H, int batch)
@@ -205,10 +205,13 @@ RansacWs carve(void* base, int width, int mw, int aux_w, int H, int batch)
     const size_t slots = (size_t)batch * H * width;
     w.models = (double*)(p + off); off += align_up(slots * mw * sizeof(double));
     w.aux = (double*)(p + off); off += align_up(slots * aux_w * sizeof(double));
+    w.list = (int32_t*)(p + off); off += align_up(slots * sizeof(int32_t));
+    w.nstart = (int32_t*)(p + off); off += align_up((size_t)batch * sizeof(int32_t));
+    w.zero_from = off;
     w.nmodels = (int32_t*)(p + off); off += align_up((size_t)batch * H * sizeof(int32_t));
     w.counts = (int32_t*)(p + off); off += align_up(slots * sizeof(int32_t));
-    w.list = (int32_t*)(p + off); off += align_up(slots * sizeof(int32_t));
     w.nlist = (int32_t*)(p + off); off += align_up((size_t)batch * sizeof(int32_t));
+    w.zero_bytes = off - w.zero_from;
     w.bytes = off;
     return w;
 }
@@ -223,12 +226,12 @@ extern "C" size_t vo_ransac_workspace_bytes(int kind, int H, int batch)
 
 extern "C" int vo_ransac_batch(int kind, const int32_t* samples, int H, const void* pts, const float* img,
                                const double* K4_host, int N, const int32_t* n_dev, int batch, float thr2,
-                               double confidence, int max_iters, int32_t* result, double* best_model,
-                               double* best_rvec, uint8_t* mask, void* workspace, size_t workspace_bytes,
-                               void* stream)
+                               double confidence, int max_iters, int first_block, int32_t* result,
+                               double* best_model, double* best_rvec, uint8_t* mask, void* workspace,
+                               size_t workspace_bytes, void* stream)
 {
     VO_CHECK_ARG(kind >= 0 && kind <= 2, VO_EINVAL, "vo_ransac_batch: kind must be 0 (F), 1 (E) or 2 (PnP)");
-    VO_CHECK_ARG(H >= 0 && N >= 0 && batch >= 0, VO_EINVAL, "vo_ransac_batch: negative size");
+    VO_CHECK_ARG(H >= 0 && N >= 0 && batch >= 0 && first_block >= 0, VO_EINVAL, "vo_ransac_batch: negative size");
     if (batch == 0) return VO_OK;
     VO_CHECK_ARG(H > 0 && N > 0, VO_EINVAL, "vo_ransac_batch: needs at least one sample and one correspondence");
     VO_CHECK_ARG(samples && pts && result && mask, VO_EINVAL, "vo_ransac_batch: null pointer");
@@ -242,30 +245,44 @@ extern "C" int vo_ransac_batch(int kind, const int32_t* samples, int H, const vo
     VO_CHECK_ARG(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= w.bytes, VO_EWORKSPACE,
                  "vo_ransac_batch: workspace of %zu bytes (16-byte aligned) required, got %zu", w.bytes, workspace_bytes);
     hipStream_t s = (hipStream_t)stream;
-    VO_HIP_TRY(hipMemsetAsync(w.nlist, 0, (size_t)batch * sizeof(int32_t), s));
+    // nmodels = 0 (iterations never solved hold no model), counts = 0, nlist = 0
+    VO_HIP_TRY(hipMemsetAsync((char*)workspace + w.zero_from, 0, w.zero_bytes, s));
     const int Htot = H * batch;
-    int rc;
-    vo_prof_begin(VO_STAGE_SOLVE, kind, s);
-    if (kind == VO_KIND_FUND)
-        rc = vo_launch_solve_7pt(samples, Htot, H, (const float*)pts, N, n_dev, w.models, w.nmodels, w.list, w.nlist, s);
-    else if (kind == VO_KIND_ESS)
-        rc = vo_launch_solve_5pt(samples, Htot, H, (const double*)pts, N, n_dev, w.models, w.nmodels, w.list, w.nlist, s);
-    else
-        rc = vo_launch_solve_p3p(samples, Htot, H, (const float*)pts, img, K4_host, N, n_dev, w.models, w.aux, w.nmodels,
-                                 w.list, w.nlist, s);
-    vo_prof_end(VO_STAGE_SOLVE, s);
-    if (rc != VO_OK) return rc;
-    rc = vo_launch_init_counts(nullptr, w.nmodels, width, (long)Htot * width, w.counts, s);
-    if (rc != VO_OK) return rc;
-    vo_prof_begin(VO_STAGE_SCORE, kind, s);
-    rc = vo_launch_score(kind, w.models, nullptr, w.list, w.nlist, H * width, pts, img, n_dev, N, batch, K4_host, thr2,
-                         w.counts, s);
-    vo_prof_end(VO_STAGE_SCORE, s);
-    if (rc != VO_OK) return rc;
-    vo_prof_begin(VO_STAGE_REPLAY, kind, s);
-    rc = vo_launch_replay(w.counts, w.nmodels, H, width, N, n_dev, kModelPoints[kind], confidence, max_iters, batch, result, s);
-    vo_prof_end(VO_STAGE_REPLAY, s);
-    if (rc != VO_OK) return rc;
+    // iteration blocks: [0, first_block), then blocks 4x as long as everything before, up to H.  After
+    // each block the replay tells which problems OpenCV's loop would already have left (niters <= block
+    // end); their later blocks cost nothing but the launch.
+    int h0 = 0;
+    for (int stage = 0; h0 < H; ++stage) {
+        int h1 = H;
+        if (first_block > 0 && first_block < H) h1 = stage == 0 ? first_block : (h0 * 5 < H ? h0 * 5 : H);
+        if (H - h1 < h1 / 4) h1 = H;                     // do not leave a sliver for a last stage
+        const int hlen = h1 - h0;
+        const int32_t* prev = stage == 0 ? nullptr : result;
+        if (stage > 0) VO_HIP_TRY(hipMemcpyAsync(w.nstart, w.nlist, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        int rc;
+        vo_prof_begin(VO_STAGE_SOLVE, kind | (stage << 8), s);
+        if (kind == VO_KIND_FUND)
+            rc = vo_launch_solve_7pt(samples, Htot, H, (const float*)pts, N, n_dev, w.models, w.nmodels, w.list, w.nlist,
+                                     h0, hlen, prev, s);
+        else if (kind == VO_KIND_ESS)
+            rc = vo_launch_solve_5pt(samples, Htot, H, (const double*)pts, N, n_dev, w.models, w.nmodels, w.list, w.nlist,
+                                     h0, hlen, prev, s);
+        else
+            rc = vo_launch_solve_p3p(samples, Htot, H, (const float*)pts, img, K4_host, N, n_dev, w.models, w.aux, w.nmodels,
+                                     w.list, w.nlist, h0, hlen, prev, s);
+        vo_prof_end(VO_STAGE_SOLVE, s);
+        if (rc != VO_OK) return rc;
+        vo_prof_begin(VO_STAGE_SCORE, kind | (stage << 8), s);
+        rc = vo_launch_score(kind, w.models, nullptr, w.list, stage == 0 ? nullptr : w.nstart, w.nlist, H * width, pts, img,
+                             n_dev, N, batch, K4_host, thr2, w.counts, hlen * width, s);
+        vo_prof_end(VO_STAGE_SCORE, s);
+        if (rc != VO_OK) return rc;
+        vo_prof_begin(VO_STAGE_REPLAY, kind | (stage << 8), s);
+        rc = vo_launch_replay(w.counts, w.nmodels, H, width, N, n_dev, kModelPoints[kind], confidence, max_iters, batch, result, s);
+        vo_prof_end(VO_STAGE_REPLAY, s);
+        if (rc != VO_OK) return rc;
+        h0 = h1;
+    }
     return vo_launch_mask_best(kind, w.models, H * width, width, aux_w ? w.aux : nullptr, aux_w, best_rvec, result, pts, img,
                                n_dev, N, batch, K4_host, thr2, mask, best_model, s);
 }

@@ -92,6 +92,7 @@ struct ScoreArgs {
     const double* models;     // batch x H x MW f64
     const uint8_t* valid;     // batch x H, may be null
     const int32_t* list;      // batch x H compacted slot list, may be null (then thread t scores slot t)
+    const int32_t* nstart;    // batch: first list entry to score (may be null = 0)
     const int32_t* nlist;     // batch entries used of list
     const void* pts;          // F: batch x N float4; E: batch x N x 4 f64; PnP: batch x N x 3 f32
     const float2* img;        // PnP only: batch x N
@@ -111,7 +112,8 @@ void score_kernel(const ScoreArgs a)
     const int b = blockIdx.z;
     const int n = a.n_dev ? min(a.n_dev[b], a.N) : a.N;
     const int p0 = blockIdx.y * a.chunk;
-    const int nslots = a.list ? a.nlist[b] : a.H;
+    const int first = a.list && a.nstart ? a.nstart[b] : 0;
+    const int nslots = a.list ? a.nlist[b] - first : a.H;
     if (p0 >= n || (int)(blockIdx.x * kThreads) >= nslots) return;      // block-uniform
     const int np = min(a.chunk, n - p0);
 
@@ -136,7 +138,7 @@ void score_kernel(const ScoreArgs a)
     const int t = blockIdx.x * kThreads + threadIdx.x;
     int slot = t;
     bool live = t < nslots;
-    if (a.list) slot = live ? a.list[(size_t)b * a.H + t] : 0;
+    if (a.list) slot = live ? a.list[(size_t)b * a.H + first + t] : 0;
     const size_t gslot = (size_t)b * a.H + slot;
     if (!a.list) live = live && (!a.valid || a.valid[gslot]);
     double M[MW];
@@ -280,18 +282,20 @@ int vo_launch_init_counts(const uint8_t* valid, const int32_t* nmodels, int slot
     return VO_OK;
 }
 
-int vo_launch_score(int kind, const double* models, const uint8_t* valid, const int32_t* list, const int32_t* nlist,
-                    int H, const void* pts, const float* img, const int32_t* n_dev, int N, int batch,
-                    const double* K4, float thr2, int32_t* counts, hipStream_t s)
+int vo_launch_score(int kind, const double* models, const uint8_t* valid, const int32_t* list, const int32_t* nstart,
+                    const int32_t* nlist, int H, const void* pts, const float* img, const int32_t* n_dev, int N, int batch,
+                    const double* K4, float thr2, int32_t* counts, int max_slots, hipStream_t s)
 {
+    // H = model slots per problem (array stride); max_slots <= H bounds how many this launch can score
     if (H == 0 || N == 0 || batch == 0) return VO_OK;
     ScoreArgs a;
-    a.models = models; a.valid = valid; a.list = list; a.nlist = nlist; a.pts = pts; a.img = (const float2*)img;
+    a.models = models; a.valid = valid; a.list = list; a.nstart = nstart; a.nlist = nlist; a.pts = pts; a.img = (const float2*)img;
     a.n_dev = n_dev; a.counts = counts; a.H = H; a.N = N; a.thr2 = thr2;
-    a.chunk = pick_chunk(H, N, batch);
+    if (max_slots <= 0 || max_slots > H) max_slots = H;
+    a.chunk = pick_chunk(max_slots, N, batch);
     a.fx = K4 ? K4[0] : 0; a.fy = K4 ? K4[1] : 0; a.cx = K4 ? K4[2] : 0; a.cy = K4 ? K4[3] : 0;
     VO_CHECK_ARG(vo_ceil_div(N, a.chunk) <= 65535 && batch <= 65535, VO_ESIZE, "score: N=%d or batch=%d too large", N, batch);
-    const dim3 grid(vo_ceil_div(H, kThreads), vo_ceil_div(N, a.chunk), batch);
+    const dim3 grid(vo_ceil_div(max_slots, kThreads), vo_ceil_div(N, a.chunk), batch);
     if (kind == kFund) hipLaunchKernelGGL(score_kernel<kFund>, grid, dim3(kThreads), 0, s, a);
     else if (kind == kEss) hipLaunchKernelGGL(score_kernel<kEss>, grid, dim3(kThreads), 0, s, a);
     else hipLaunchKernelGGL(score_kernel<kPnp>, grid, dim3(kThreads), 0, s, a);
@@ -332,7 +336,7 @@ extern "C" int vo_score_fund(const double* models, const uint8_t* valid, int H, 
     int rc = vo_launch_init_counts(valid, nullptr, 1, H, counts, s);
     if (rc != VO_OK || N == 0) return rc;
     VO_CHECK_ARG(pts && ((uintptr_t)pts & 15) == 0, VO_EINVAL, "vo_score_fund: pts null or not 16-byte aligned");
-    return vo_launch_score(kFund, models, valid, nullptr, nullptr, H, pts, nullptr, nullptr, N, 1, nullptr, thr2, counts, s);
+    return vo_launch_score(kFund, models, valid, nullptr, nullptr, nullptr, H, pts, nullptr, nullptr, N, 1, nullptr, thr2, counts, H, s);
 }
 
 extern "C" int vo_score_ess(const double* models, const uint8_t* valid, int H, const double* pts, int N,
@@ -343,7 +347,7 @@ extern "C" int vo_score_ess(const double* models, const uint8_t* valid, int H, c
     int rc = vo_launch_init_counts(valid, nullptr, 1, H, counts, s);
     if (rc != VO_OK || N == 0) return rc;
     VO_CHECK_ARG(pts != nullptr, VO_EINVAL, "vo_score_ess: null pts");
-    return vo_launch_score(kEss, models, valid, nullptr, nullptr, H, pts, nullptr, nullptr, N, 1, nullptr, thr2, counts, s);
+    return vo_launch_score(kEss, models, valid, nullptr, nullptr, nullptr, H, pts, nullptr, nullptr, N, 1, nullptr, thr2, counts, H, s);
 }
 
 extern "C" int vo_score_pnp(const double* models, const uint8_t* valid, int H, const float* obj,
@@ -356,7 +360,7 @@ extern "C" int vo_score_pnp(const double* models, const uint8_t* valid, int H, c
     if (rc != VO_OK || N == 0) return rc;
     VO_CHECK_ARG(obj && img && K4_host, VO_EINVAL, "vo_score_pnp: null pointer");
     VO_CHECK_ARG(((uintptr_t)img & 7) == 0, VO_EINVAL, "vo_score_pnp: img must be 8-byte aligned");
-    return vo_launch_score(kPnp, models, valid, nullptr, nullptr, H, obj, img, nullptr, N, 1, K4_host, thr2, counts, s);
+    return vo_launch_score(kPnp, models, valid, nullptr, nullptr, nullptr, H, obj, img, nullptr, N, 1, K4_host, thr2, counts, H, s);
 }
 
 extern "C" int vo_mask_fund(const double* model, const float* pts, int N, float thr2, uint8_t* mask, void* stream)

@@ -194,12 +194,18 @@ __device__ int solve_cubic(double a0, double a1, double a2, double a3, double* r
 __global__ __launch_bounds__(kLanes)
 void solve_7pt_kernel(const int32_t* __restrict__ samples, int H, const float4* __restrict__ pts, int N,
                       double* __restrict__ models, int32_t* __restrict__ nmodels,
-                      int per, int32_t* __restrict__ list, int32_t* __restrict__ nlist, const int32_t* __restrict__ n_dev)
+                      int per, int32_t* __restrict__ list, int32_t* __restrict__ nlist, const int32_t* __restrict__ n_dev,
+                      int h0, int hlen, const int32_t* __restrict__ prev)
 {
     __shared__ double lds[(81 + 9) * kLanes];
-    const int h = blockIdx.x * kLanes + threadIdx.x;
-    const bool live = h < H;
-    const int b = live ? h / per : 0;                 // problem this sample belongs to
+    // thread -> (problem b, iteration h0 + i) for the iteration block [h0, h0 + hlen) of every problem;
+    // a problem whose sequential loop already ended (prev = its replay result, niters <= h0) is skipped
+    const int tix = blockIdx.x * kLanes + threadIdx.x;
+    bool live = tix < (H / per) * hlen;
+    const int b = live ? tix / hlen : 0;
+    const int h = b * per + h0 + (tix - b * hlen);
+    if (prev && prev[4 * b + 3] <= h0) live = false;
+    if (!__any(live)) return;                 // problem this sample belongs to
     const int nb_pts = n_dev ? min(n_dev[b], N) : N;
     pts += (size_t)b * N;
     const SV A{lds + threadIdx.x}, W{lds + 81 * kLanes + threadIdx.x};
@@ -611,12 +617,18 @@ __global__ __launch_bounds__(kLanes)
 void solve_p3p_kernel(const int32_t* __restrict__ samples, int H, const float* __restrict__ obj,
                       const float2* __restrict__ img, int N, double fx, double fy, double cx, double cy,
                       double* __restrict__ models, double* __restrict__ rvecs, int32_t* __restrict__ nmodels,
-                      int per, int32_t* __restrict__ list, int32_t* __restrict__ nlist, const int32_t* __restrict__ n_dev)
+                      int per, int32_t* __restrict__ list, int32_t* __restrict__ nlist, const int32_t* __restrict__ n_dev,
+                      int h0, int hlen, const int32_t* __restrict__ prev)
 {
     __shared__ double lds[21 * kLanes];
-    const int h = blockIdx.x * kLanes + threadIdx.x;
-    const bool live = h < H;
-    const int b = live ? h / per : 0;
+    // thread -> (problem b, iteration h0 + i) for the iteration block [h0, h0 + hlen) of every problem;
+    // a problem whose sequential loop already ended (prev = its replay result, niters <= h0) is skipped
+    const int tix = blockIdx.x * kLanes + threadIdx.x;
+    bool live = tix < (H / per) * hlen;
+    const int b = live ? tix / hlen : 0;
+    const int h = b * per + h0 + (tix - b * hlen);
+    if (prev && prev[4 * b + 3] <= h0) live = false;
+    if (!__any(live)) return;
     const int nb_pts = n_dev ? min(n_dev[b], N) : N;
     obj += (size_t)b * N * 3;
     img += (size_t)b * N;
@@ -821,12 +833,18 @@ __device__ int solve_poly(const double* coeffs, int deg, double* re, double* im)
 __global__ __launch_bounds__(kLanes)
 void solve_5pt_kernel(const int32_t* __restrict__ samples, int H, const double* __restrict__ pts, int N,
                       double* __restrict__ models, int32_t* __restrict__ nmodels,
-                      int per, int32_t* __restrict__ list, int32_t* __restrict__ nlist, const int32_t* __restrict__ n_dev)
+                      int per, int32_t* __restrict__ list, int32_t* __restrict__ nlist, const int32_t* __restrict__ n_dev,
+                      int h0, int hlen, const int32_t* __restrict__ prev)
 {
     __shared__ double lds[(81 + 9) * kLanes];
-    const int h = blockIdx.x * kLanes + threadIdx.x;
-    const bool live = h < H;
-    const int b = live ? h / per : 0;
+    // thread -> (problem b, iteration h0 + i) for the iteration block [h0, h0 + hlen) of every problem;
+    // a problem whose sequential loop already ended (prev = its replay result, niters <= h0) is skipped
+    const int tix = blockIdx.x * kLanes + threadIdx.x;
+    bool live = tix < (H / per) * hlen;
+    const int b = live ? tix / hlen : 0;
+    const int h = b * per + h0 + (tix - b * hlen);
+    if (prev && prev[4 * b + 3] <= h0) live = false;
+    if (!__any(live)) return;
     const int nb_pts = n_dev ? min(n_dev[b], N) : N;
     pts += (size_t)b * N * 4;
     const SV A9{lds + threadIdx.x}, W{lds + 81 * kLanes + threadIdx.x};
@@ -962,29 +980,35 @@ void solve_5pt_kernel(const int32_t* __restrict__ samples, int H, const double* 
 // internal launchers shared with the fused batched pipelines in vo_ransac.hip.  H = total samples
 // (all problems), per = samples per problem, N = correspondences per problem (array stride).
 int vo_launch_solve_7pt(const int32_t* samples, int H, int per, const float* pts, int N, const int32_t* n_dev,
-                        double* models, int32_t* nmodels, int32_t* list, int32_t* nlist, hipStream_t s)
+                        double* models, int32_t* nmodels, int32_t* list, int32_t* nlist, int h0, int hlen,
+                        const int32_t* prev, hipStream_t s)
 {
-    hipLaunchKernelGGL(solve_7pt_kernel, dim3(vo_ceil_div(H, kLanes)), dim3(kLanes), 0, s, samples, H,
-                       (const float4*)pts, N, models, nmodels, per, list, nlist, n_dev);
+    if (hlen <= 0) return VO_OK;
+    hipLaunchKernelGGL(solve_7pt_kernel, dim3(vo_ceil_div((H / per) * hlen, kLanes)), dim3(kLanes), 0, s, samples, H,
+                       (const float4*)pts, N, models, nmodels, per, list, nlist, n_dev, h0, hlen, prev);
     VO_LAUNCH_CHECK();
     return VO_OK;
 }
 
 int vo_launch_solve_5pt(const int32_t* samples, int H, int per, const double* pts, int N, const int32_t* n_dev,
-                        double* models, int32_t* nmodels, int32_t* list, int32_t* nlist, hipStream_t s)
+                        double* models, int32_t* nmodels, int32_t* list, int32_t* nlist, int h0, int hlen,
+                        const int32_t* prev, hipStream_t s)
 {
-    hipLaunchKernelGGL(solve_5pt_kernel, dim3(vo_ceil_div(H, kLanes)), dim3(kLanes), 0, s, samples, H, pts, N,
-                       models, nmodels, per, list, nlist, n_dev);
+    if (hlen <= 0) return VO_OK;
+    hipLaunchKernelGGL(solve_5pt_kernel, dim3(vo_ceil_div((H / per) * hlen, kLanes)), dim3(kLanes), 0, s, samples, H, pts, N,
+                       models, nmodels, per, list, nlist, n_dev, h0, hlen, prev);
     VO_LAUNCH_CHECK();
     return VO_OK;
 }
 
 int vo_launch_solve_p3p(const int32_t* samples, int H, int per, const float* obj, const float* img, const double* K4,
                         int N, const int32_t* n_dev, double* models, double* rvecs, int32_t* nmodels, int32_t* list,
-                        int32_t* nlist, hipStream_t s)
+                        int32_t* nlist, int h0, int hlen, const int32_t* prev, hipStream_t s)
 {
-    hipLaunchKernelGGL(solve_p3p_kernel, dim3(vo_ceil_div(H, kLanes)), dim3(kLanes), 0, s, samples, H, obj,
-                       (const float2*)img, N, K4[0], K4[1], K4[2], K4[3], models, rvecs, nmodels, per, list, nlist, n_dev);
+    if (hlen <= 0) return VO_OK;
+    hipLaunchKernelGGL(solve_p3p_kernel, dim3(vo_ceil_div((H / per) * hlen, kLanes)), dim3(kLanes), 0, s, samples, H, obj,
+                       (const float2*)img, N, K4[0], K4[1], K4[2], K4[3], models, rvecs, nmodels, per, list, nlist, n_dev,
+                       h0, hlen, prev);
     VO_LAUNCH_CHECK();
     return VO_OK;
 }
@@ -1000,7 +1024,7 @@ extern "C" int vo_solve_7pt(const int32_t* samples, int H, const float* pts, int
 {
     SOLVE_ARG_CHECKS("vo_solve_7pt");
     VO_CHECK_ARG(pts && ((uintptr_t)pts & 15) == 0, VO_EINVAL, "vo_solve_7pt: pts null or not 16-byte aligned");
-    return vo_launch_solve_7pt(samples, H, H, pts, N, nullptr, models, nmodels, nullptr, nullptr, (hipStream_t)stream);
+    return vo_launch_solve_7pt(samples, H, H, pts, N, nullptr, models, nmodels, nullptr, nullptr, 0, H, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int vo_solve_5pt(const int32_t* samples, int H, const double* pts, int N, double* models,
@@ -1008,7 +1032,7 @@ extern "C" int vo_solve_5pt(const int32_t* samples, int H, const double* pts, in
 {
     SOLVE_ARG_CHECKS("vo_solve_5pt");
     VO_CHECK_ARG(pts != nullptr, VO_EINVAL, "vo_solve_5pt: null pts");
-    return vo_launch_solve_5pt(samples, H, H, pts, N, nullptr, models, nmodels, nullptr, nullptr, (hipStream_t)stream);
+    return vo_launch_solve_5pt(samples, H, H, pts, N, nullptr, models, nmodels, nullptr, nullptr, 0, H, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int vo_solve_p3p(const int32_t* samples, int H, const float* obj, const float* img,
@@ -1019,5 +1043,5 @@ extern "C" int vo_solve_p3p(const int32_t* samples, int H, const float* obj, con
     VO_CHECK_ARG(obj && img && K4_host && rvecs && ((uintptr_t)img & 7) == 0, VO_EINVAL,
                  "vo_solve_p3p: null/unaligned pointer");
     return vo_launch_solve_p3p(samples, H, H, obj, img, K4_host, N, nullptr, models, rvecs, nmodels, nullptr, nullptr,
-                               (hipStream_t)stream);
+                               0, H, nullptr, (hipStream_t)stream);
 }

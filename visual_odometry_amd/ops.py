@@ -252,11 +252,13 @@ _SAMPLE_WIDTH = {KIND_FUND: 7, KIND_ESS: 5, KIND_PNP: 4}
 
 def ransac_batch(kind: int, samples: torch.Tensor, pts: torch.Tensor, threshold: float, confidence: float,
                  max_iters: int, img: Optional[torch.Tensor] = None, K=None, n_dev: Optional[torch.Tensor] = None,
-                 workspace: Optional[torch.Tensor] = None):
+                 workspace: Optional[torch.Tensor] = None, first_block: int = 0):
     """Fused solve -> score -> replay -> mask for a batch of same-shape problems, no host sync.
 
     samples (B,H,m) i32; pts (B,N,4) f32 [F] | (B,N,4) f64 [E] | (B,N,3) f32 object points [PnP, with
-    img (B,N,2) f32 and K].  -> result (B,4) i32, best_model (B,9|12) f64, best_rvec (B,3) f64 | None,
+    img (B,N,2) f32 and K].  first_block > 0: iterations are evaluated in growing blocks and problems
+    whose adaptive iteration count is already reached skip the rest (same results).
+    -> result (B,4) i32, best_model (B,9|12) f64, best_rvec (B,3) f64 | None,
     mask (B,N) u8."""
     _lib.require_device()
     lib = _lib.load()
@@ -287,7 +289,7 @@ def ransac_batch(kind: int, samples: torch.Tensor, pts: torch.Tensor, threshold:
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty((need,), dtype=torch.uint8, device=dev)
     _lib.check(lib.vo_ransac_batch(kind, _ptr(samples), H, _ptr(pts), img_p, k4, N, _ptr(nd), B, thr2_of(threshold),
-                                   float(confidence), int(max_iters), _ptr(result), _ptr(best), _ptr(rvec), _ptr(mask),
+                                   float(confidence), int(max_iters), int(first_block), _ptr(result), _ptr(best), _ptr(rvec), _ptr(mask),
                                    _ptr(workspace), workspace.numel() * workspace.element_size(), _stream()),
                "vo_ransac_batch")
     return result, best, rvec, mask
