@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=16, help="frame pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=64, help="frame pairs per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -227,7 +227,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as fh:
             tj = json.load(fh)
-        if args.pairs == 16:
+        if args.pairs == tj.get("_pairs", 16):
             traffic = {k: v["hbm_bytes_per_launch"] for k, v in tj.items() if isinstance(v, dict)}
     except (OSError, ValueError, KeyError):
         pass

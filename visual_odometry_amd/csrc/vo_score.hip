@@ -146,7 +146,7 @@ void score_kernel(const ScoreArgs a)
     for (int k = 0; k < MW; ++k) M[k] = live ? a.models[gslot * MW + k] : 0.;
     __syncthreads();
     int cnt = 0;
-    for (int i = 0; i < np; ++i) {
+    auto one = [&](int i) {
         const double2 u = *(const double2*)(sp + 4 * i);
         if (KIND == kPnp) {
             const double Z = sp[4 * i + 2];
@@ -156,7 +156,14 @@ void score_kernel(const ScoreArgs a)
             const double2 v = *(const double2*)(sp + 4 * i + 2);
             cnt += (KIND == kFund ? fund_err(M, u.x, u.y, v.x, v.y) : sampson_err(M, u.x, u.y, v.x, v.y)) <= a.thr2;
         }
+    };
+    // four correspondences per trip: the loop bookkeeping (and the LDS wait) is paid once per four
+    // error evaluations; each evaluation itself is unchanged
+    int i = 0;
+    for (; i + 4 <= np; i += 4) {
+        one(i); one(i + 1); one(i + 2); one(i + 3);
     }
+    for (; i < np; ++i) one(i);
     if (live && cnt) atomicAdd(a.counts + gslot, cnt);
 }
 
