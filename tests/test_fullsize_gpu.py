@@ -1,0 +1,81 @@
+"""GPU parity at BASELINE.json's full sizes (configs 4 and 5).  Exhaustive oracle runs are too slow
+there for the RANSAC part, so these use what stays cheap: the multi-threaded oracle matcher on the
+whole 32768 x 32768 problem (about a second), exact scoring of a SAMPLE of hypotheses, and
+size-independent properties (row independence under sharding, replay against the oracle)."""
+import numpy as np
+import pytest
+import torch
+
+from visual_odometry_amd import ops, parallel, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _d(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _knn(q, t, dev):
+    qi8, qn, _ = ops.desc_to_i8(_d(q, dev)); ti8, tn, _ = ops.desc_to_i8(_d(t, dev))
+    idx, d2 = ops.knn2(qi8, qn, ti8, tn)
+    return idx.cpu().numpy(), d2.cpu().numpy(), (qi8, qn, ti8, tn)
+
+
+def test_knn_32768_full(oracle_mod, dev):
+    q, t = synth.sift_like_pair(32768, 32768, seed=555)
+    t[1000] = t[7]; t[20000] = t[7]; q[3] = t[7]                 # a three-way exact tie far apart
+    idx, d2, (qi8, qn, ti8, tn) = _knn(q, t, dev)
+    oi, od = oracle_mod.knn2(q, t, mt=True)
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(np.sqrt(d2.astype(np.float32)), od)
+    assert tuple(idx[3]) == (7, 1000)
+    # sharding query rows over "ranks" changes nothing (rows are independent): config 4's layout
+    parts = []
+    for r in range(4):
+        lo, hi = parallel.shard_bounds(32768, r, 4)
+        i2, _ = ops.knn2(qi8[lo:hi], qn[lo:hi], ti8, tn)
+        parts.append(i2.cpu().numpy())
+    assert np.array_equal(np.concatenate(parts), idx)
+
+
+def test_pnp_65536_hypotheses_32768_points(det_math, dev):
+    """config 5's RANSAC shape: counts of a sample of hypotheses and the replay decision."""
+    o = det_math
+    N, H = 32768, 65536
+    ps = synth.pnp_scene(N, seed=77, outlier_frac=0.5, noise_px=0.5)
+    obj, img, K = ps["obj"], ps["img"], ps["K"]
+    subs = ops.gen_subsets(N, 4, H)
+    assert np.array_equal(subs[:2000], o.gen_subsets(N, 4, 2000))
+    models, rvecs, nm = ops.solve_p3p(_d(subs, dev), _d(obj, dev), _d(img, dev), K)
+    counts = ops.score_pnp(models, _d(obj, dev), _d(img, dev), K, 1.0, nm.to(torch.uint8))
+    res = ops.ransac_replay(counts, nm, N, 4, 0.9999, H).cpu().numpy()
+    counts_h, nm_h, models_h = counts.cpu().numpy(), nm.cpu().numpy(), models.cpu().numpy()
+    rng = np.random.default_rng(1)
+    sample = list(rng.choice(H, 40, replace=False)) + [int(res[0])]
+    for h in sample:
+        ns, rv, tv, R = o.p3p_kernel(obj[subs[h]], img[subs[h]], K)
+        assert (ns > 0) == (nm_h[h] > 0)
+        if ns > 0:
+            assert np.array_equal(models_h[h], np.concatenate([R.reshape(9), tv]))
+            assert counts_h[h] == o.find_inliers(o.pnp_error(R, tv, K, obj, img), 1.0)[0]
+        else:
+            assert counts_h[h] == -1
+    assert tuple(int(v) for v in res) == o.ransac_replay(counts_h.reshape(-1, 1), nm_h, N, 4, 0.9999, H)
+    # the fused, early-terminating path reaches the same decision
+    r2, best, rv2, mask = ops.ransac_batch(ops.KIND_PNP, _d(subs[None], dev), _d(obj[None], dev), 1.0, 0.9999, H,
+                                           img=_d(img[None], dev), K=K, first_block=256)
+    assert np.array_equal(r2.cpu().numpy()[0], res)
+    assert np.array_equal(best.cpu().numpy()[0], models_h[res[0]])
+    m = models_h[res[0]]
+    assert np.array_equal(mask.cpu().numpy()[0], o.find_inliers(o.pnp_error(m[:9], m[9:], K, obj, img), 1.0)[1])
+    assert mask.sum().item() == res[2]
+
+
+def test_fund_4096_hypotheses_8192_points(det_math, dev):
+    """config 4's F-RANSAC shape (8192 correspondences, 4096 samples) end to end against the oracle."""
+    from visual_odometry_amd import ransac
+    sc = synth.two_view_scene(8192, seed=88, outlier_frac=0.4)
+    F, mask, info = ransac.find_fundamental_ransac(sc["p1"], sc["p2"], 0.1, 0.9999, 4096)
+    oF, omask, oinfo = det_math.find_fundamental_mat(sc["p1"], sc["p2"], 0.1, 0.9999, 4096)
+    assert (info.best_iter, info.best_model, info.max_good, info.niters) == tuple(int(v) for v in oinfo)
+    assert np.array_equal(mask, omask) and np.array_equal(F, oF)
