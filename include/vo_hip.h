@@ -166,6 +166,31 @@ int vo_ransac_batch(int kind, const int32_t* samples, int H, const void* pts, co
                     double* best_model, double* best_rvec, uint8_t* mask, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Keeping a frame pair on the device between matching and RANSAC.
+ * ---------------------------------------------------------------------------------- */
+
+/* The gathers of reference src/features.py:110-122 / src/twoDtwoD.py:54-55 as an ordered stream
+ * compaction, `batch` pairs per launch.  idx batch x nq x 2 (vo_knn2_l2_i8), keep batch x nq
+ * (vo_ratio_test), kp_q batch x nq x 2 f32 and kp_t batch x nt x 2 f32 keypoint positions, xyz_q
+ * batch x nq x 3 f32 landmarks of the query keypoints (NULL if none).  Outputs, all batch x nq
+ * rows with the first n_match[b] used, ascending query index: match_q / match_t (row indices),
+ * pts4 (x_q y_q x_t y_t: the F / E correspondences), obj + img (landmark of the query keypoint and
+ * position of its match: the PnP correspondences of src/sift_test.py:104-119).  pts4, obj, img may
+ * each be NULL. */
+int vo_match_compact(const int32_t* idx, const uint8_t* keep, int nq, int nt, int batch,
+                     const float* kp_q, const float* kp_t, const float* xyz_q,
+                     int32_t* match_q, int32_t* match_t, int32_t* n_match,
+                     float* pts4, float* obj, float* img, void* stream);
+
+/* vo_host_gen_subsets on the device, for correspondence counts that only exist there: n_dev batch
+ * x int32 (NULL = N everywhere), N the stride of pts4 (batch x N x 4 f32; NULL = no checkSubset,
+ * i.e. the E / PnP estimators).  samples batch x H x model_points; iterations after getSubset gave
+ * up are filled with -1 (the solvers treat them as "no sample"), n_generated (batch, may be NULL)
+ * receives how many were produced.  model_points 4, 5 or 7. */
+int vo_gen_subsets_device(const int32_t* n_dev, int N, int model_points, int H, const float* pts4,
+                          int batch, int32_t* samples, int32_t* n_generated, void* stream);
+
 /* result (2 x int32): largest count and the lowest index holding it (pure argmax mode). */
 int vo_argmax_first(const int32_t* counts, int n, int32_t* result, void* stream);
 

@@ -205,6 +205,7 @@ void solve_7pt_kernel(const int32_t* __restrict__ samples, int H, const float4* 
     const int b = live ? tix / hlen : 0;
     const int h = b * per + h0 + (tix - b * hlen);
     if (prev && prev[4 * b + 3] <= h0) live = false;
+    if (live && samples[(size_t)h * 7] < 0) live = false;     // iteration without a sample (getSubset gave up)
     if (!__any(live)) return;                 // problem this sample belongs to
     const int nb_pts = n_dev ? min(n_dev[b], N) : N;
     pts += (size_t)b * N;
@@ -628,6 +629,7 @@ void solve_p3p_kernel(const int32_t* __restrict__ samples, int H, const float* _
     const int b = live ? tix / hlen : 0;
     const int h = b * per + h0 + (tix - b * hlen);
     if (prev && prev[4 * b + 3] <= h0) live = false;
+    if (live && samples[(size_t)h * 4] < 0) live = false;     // iteration without a sample (getSubset gave up)
     if (!__any(live)) return;
     const int nb_pts = n_dev ? min(n_dev[b], N) : N;
     obj += (size_t)b * N * 3;
@@ -844,6 +846,7 @@ void solve_5pt_kernel(const int32_t* __restrict__ samples, int H, const double* 
     const int b = live ? tix / hlen : 0;
     const int h = b * per + h0 + (tix - b * hlen);
     if (prev && prev[4 * b + 3] <= h0) live = false;
+    if (live && samples[(size_t)h * 5] < 0) live = false;     // iteration without a sample (getSubset gave up)
     if (!__any(live)) return;
     const int nb_pts = n_dev ? min(n_dev[b], N) : N;
     pts += (size_t)b * N * 4;

@@ -295,6 +295,50 @@ def ransac_batch(kind: int, samples: torch.Tensor, pts: torch.Tensor, threshold:
     return result, best, rvec, mask
 
 
+def match_compact(idx: torch.Tensor, keep: torch.Tensor, kp_q: torch.Tensor, kp_t: torch.Tensor,
+                  xyz_q: Optional[torch.Tensor] = None, want_pts4: bool = True):
+    """idx (B,nq,2) i32, keep (B,nq) u8, kp_q (B,nq,2) f32, kp_t (B,nt,2) f32, xyz_q (B,nq,3) f32 | None
+    -> dict(match_q, match_t (B,nq) i32, n (B,) i32, pts4 (B,nq,4) f32 | None, obj (B,nq,3), img (B,nq,2) | None);
+    rows beyond n[b] are unspecified."""
+    _lib.require_device()
+    idx = _dev(idx, torch.int32, "idx"); keep = _dev(keep, torch.uint8, "keep")
+    kp_q = _dev(kp_q, torch.float32, "kp_q"); kp_t = _dev(kp_t, torch.float32, "kp_t")
+    B, nq, nt = idx.shape[0], idx.shape[1], kp_t.shape[1]
+    if tuple(keep.shape) != (B, nq) or tuple(kp_q.shape) != (B, nq, 2) or kp_t.shape[0] != B:
+        raise _lib.VoError("match_compact: shape mismatch")
+    dev = idx.device
+    mq = torch.empty((B, nq), dtype=torch.int32, device=dev); mt = torch.empty_like(mq)
+    n = torch.empty((B,), dtype=torch.int32, device=dev)
+    pts4 = torch.empty((B, nq, 4), dtype=torch.float32, device=dev) if want_pts4 else None
+    obj = img = None
+    if xyz_q is not None:
+        xyz_q = _dev(xyz_q, torch.float32, "xyz_q")
+        obj = torch.empty((B, nq, 3), dtype=torch.float32, device=dev)
+        img = torch.empty((B, nq, 2), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().vo_match_compact(_ptr(idx), _ptr(keep), nq, nt, B, _ptr(kp_q), _ptr(kp_t), _ptr(xyz_q), _ptr(mq),
+                                            _ptr(mt), _ptr(n), _ptr(pts4), _ptr(obj), _ptr(img), _stream()), "vo_match_compact")
+    return dict(match_q=mq, match_t=mt, n=n, pts4=pts4, obj=obj, img=img)
+
+
+def gen_subsets_device(n_dev: Optional[torch.Tensor], N: int, model_points: int, H: int,
+                       pts4: Optional[torch.Tensor] = None, batch: Optional[int] = None):
+    """cv::RNG + getSubset on the device -> samples (B,H,model_points) i32 (-1 rows = none), n_generated (B,) i32."""
+    _lib.require_device()
+    if n_dev is not None:
+        n_dev = _dev(n_dev, torch.int32, "n_dev"); B = n_dev.numel(); dev = n_dev.device
+    else:
+        B = pts4.shape[0] if pts4 is not None else int(batch); dev = pts4.device if pts4 is not None else torch.device("cuda", torch.cuda.current_device())
+    if pts4 is not None:
+        pts4 = _dev(pts4, torch.float32, "pts4")
+        if pts4.shape[0] != B or pts4.shape[1] != N or pts4.shape[2] != 4:
+            raise _lib.VoError("gen_subsets_device: pts4 must be (B,N,4)")
+    samples = torch.empty((B, H, model_points), dtype=torch.int32, device=dev)
+    ngen = torch.empty((B,), dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().vo_gen_subsets_device(_ptr(n_dev), int(N), int(model_points), int(H), _ptr(pts4), B, _ptr(samples),
+                                                 _ptr(ngen), _stream()), "vo_gen_subsets_device")
+    return samples, ngen
+
+
 # ------------------------------------------------------------------------------- host helpers
 def gen_subsets(n_points: int, model_points: int, max_iters: int, pts4_host: Optional[np.ndarray] = None) -> np.ndarray:
     """cv::RNG((uint64)-1) + getSubset sample stream (host only). (n_generated, model_points) i32."""

@@ -1,0 +1,65 @@
+"""Frame pairs end to end on the device: descriptors and keypoint positions in,
+match lists, F-RANSAC and PnP-RANSAC results out, with no host round trip in between.  This is the
+batched form of the reference chain  match_features -> get_positions -> calc_fundamental_mat
+(src/twoDtwoD.py:49-57)  and  match_features -> pnp  (src/sift_test.py:104-119, src/pnp.py:13-41)
+for many pairs of one shape; the single-pair, host-array entry points live in ``features``,
+``utils.geometry`` and ``pnp``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+@dataclass
+class PairBatchResult:
+    idx: torch.Tensor            # (B,nq,2) i32   two nearest train rows of every query row
+    d2: torch.Tensor             # (B,nq,2) i32   their exact squared distances
+    match_q: torch.Tensor        # (B,nq) i32     query rows that pass the ratio test, ascending; first n_match used
+    match_t: torch.Tensor        # (B,nq) i32     their matches
+    n_match: torch.Tensor        # (B,) i32
+    pts4: torch.Tensor           # (B,nq,4) f32   matched positions x_q y_q x_t y_t
+    f_result: torch.Tensor       # (B,4) i32      best iteration, best model, inliers, final niters
+    F: torch.Tensor              # (B,9) f64
+    f_mask: torch.Tensor         # (B,nq) u8      over the matched correspondences
+    p_result: Optional[torch.Tensor] = None
+    pose: Optional[torch.Tensor] = None          # (B,12) f64 [R|t] of the best P3P model (before the EPnP refit)
+    rvec: Optional[torch.Tensor] = None          # (B,3) f64
+    p_mask: Optional[torch.Tensor] = None        # (B,nq) u8
+
+
+def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Tensor, kp_t: torch.Tensor, ratio: float,
+                     f_threshold: float, f_confidence: float, f_iters: int,
+                     xyz_q: Optional[torch.Tensor] = None, K=None, p_threshold: float = 1.0, p_confidence: float = 0.9999,
+                     p_iters: int = 0, first_block: int = 0, workspace: Optional[torch.Tensor] = None) -> PairBatchResult:
+    """desc_* (B,n,128) f32 integer-valued, kp_* (B,n,2) f32, xyz_q (B,nq,3) f32 landmarks of the query
+    keypoints (enables the PnP run when p_iters > 0).  Everything is enqueued on the current stream.
+
+    Per pair the RANSAC runs see exactly the correspondences, in the order, that the reference's
+    gathers would hand to cv2 -- so results equal the single-pair entry points'.  Pairs with fewer
+    than 15 (F) / 5 (PnP) matches get no model (the reference's cv2 calls switch algorithm or fail
+    there)."""
+    B, nq, nt = desc_q.shape[0], desc_q.shape[1], desc_t.shape[1]
+    qi8, qn, _ = ops.desc_to_i8(desc_q.reshape(B * nq, 128))
+    ti8, tn, _ = ops.desc_to_i8(desc_t.reshape(B * nt, 128))
+    idx, d2 = ops.knn2(qi8.reshape(B, nq, 128), qn.reshape(B, nq), ti8.reshape(B, nt, 128), tn.reshape(B, nt), workspace)
+    keep, _ = ops.ratio_test(d2.reshape(B * nq, 2), ratio)
+    c = ops.match_compact(idx, keep.reshape(B, nq), kp_q, kp_t, xyz_q if p_iters > 0 else None)
+    n = c["n"]
+    # fewer than 15 matches: OpenCV would not run 7-point RANSAC; feed an empty problem instead
+    n_f = torch.where(n >= 15, n, torch.zeros_like(n))
+    f_samples, _ = ops.gen_subsets_device(n_f, nq, 7, f_iters, c["pts4"])
+    f_res, F, _, f_mask = ops.ransac_batch(ops.KIND_FUND, f_samples, c["pts4"], f_threshold, f_confidence, f_iters,
+                                           n_dev=n_f, workspace=workspace, first_block=first_block)
+    out = PairBatchResult(idx, d2, c["match_q"], c["match_t"], n, c["pts4"], f_res, F, f_mask)
+    if p_iters > 0 and xyz_q is not None:
+        n_p = torch.where(n >= 5, n, torch.zeros_like(n))
+        p_samples, _ = ops.gen_subsets_device(n_p, nq, 4, p_iters, None)
+        p_res, pose, rvec, p_mask = ops.ransac_batch(ops.KIND_PNP, p_samples, c["obj"], p_threshold, p_confidence, p_iters,
+                                                     img=c["img"], K=K, n_dev=n_p, workspace=workspace, first_block=first_block)
+        out.p_result, out.pose, out.rvec, out.p_mask = p_res, pose, rvec, p_mask
+    return out
