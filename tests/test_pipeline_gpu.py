@@ -88,7 +88,7 @@ def test_pair_pipeline_matches_oracle_chain(det_math, dev):
     st = lambda k: _d(np.stack([p[k] for p in pairs]), dev)
     K = synth.K_MALAGA
     r = pipeline.match_and_ransac(st(0), st(1), st(2), st(3), 0.8, 1.0, 0.999, Hf, xyz_q=st(4), K=K, p_threshold=2.0,
-                                  p_confidence=0.999, p_iters=Hp, first_block=64)
+                                  p_confidence=0.999, p_iters=Hp, first_block_f=64, first_block_pnp=64)
     n = r.n_match.cpu().numpy()
     for b, (q, t, kq, kt, xyz) in enumerate(pairs):
         oq, ot, _, _ = o.match_features_indices(q, t, 0.8)

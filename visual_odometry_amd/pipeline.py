@@ -30,14 +30,20 @@ class PairBatchResult:
     pose: Optional[torch.Tensor] = None          # (B,12) f64 [R|t] of the best P3P model (before the EPnP refit)
     rvec: Optional[torch.Tensor] = None          # (B,3) f64
     p_mask: Optional[torch.Tensor] = None        # (B,nq) u8
+    f_samples: Optional[torch.Tensor] = None     # (B,f_iters,7) i32 the sample streams used
+    p_samples: Optional[torch.Tensor] = None
+    obj: Optional[torch.Tensor] = None           # (B,nq,3) f32 / (B,nq,2) f32: the PnP correspondences
+    img: Optional[torch.Tensor] = None
 
 
 def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Tensor, kp_t: torch.Tensor, ratio: float,
                      f_threshold: float, f_confidence: float, f_iters: int,
                      xyz_q: Optional[torch.Tensor] = None, K=None, p_threshold: float = 1.0, p_confidence: float = 0.9999,
-                     p_iters: int = 0, first_block: int = 0, workspace: Optional[torch.Tensor] = None) -> PairBatchResult:
+                     p_iters: int = 0, first_block_f: int = 0, first_block_pnp: int = 0,
+                     workspace: Optional[torch.Tensor] = None) -> PairBatchResult:
     """desc_* (B,n,128) f32 integer-valued, kp_* (B,n,2) f32, xyz_q (B,nq,3) f32 landmarks of the query
-    keypoints (enables the PnP run when p_iters > 0).  Everything is enqueued on the current stream.
+    keypoints (enables the PnP run when p_iters > 0).  first_block_*: see ops.ransac_batch (0 = evaluate all
+    iterations at once).  Everything is enqueued on the current stream.
 
     Per pair the RANSAC runs see exactly the correspondences, in the order, that the reference's
     gathers would hand to cv2 -- so results equal the single-pair entry points'.  Pairs with fewer
@@ -54,12 +60,13 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
     n_f = torch.where(n >= 15, n, torch.zeros_like(n))
     f_samples, _ = ops.gen_subsets_device(n_f, nq, 7, f_iters, c["pts4"])
     f_res, F, _, f_mask = ops.ransac_batch(ops.KIND_FUND, f_samples, c["pts4"], f_threshold, f_confidence, f_iters,
-                                           n_dev=n_f, workspace=workspace, first_block=first_block)
-    out = PairBatchResult(idx, d2, c["match_q"], c["match_t"], n, c["pts4"], f_res, F, f_mask)
+                                           n_dev=n_f, workspace=workspace, first_block=first_block_f)
+    out = PairBatchResult(idx, d2, c["match_q"], c["match_t"], n, c["pts4"], f_res, F, f_mask, f_samples=f_samples)
     if p_iters > 0 and xyz_q is not None:
         n_p = torch.where(n >= 5, n, torch.zeros_like(n))
         p_samples, _ = ops.gen_subsets_device(n_p, nq, 4, p_iters, None)
         p_res, pose, rvec, p_mask = ops.ransac_batch(ops.KIND_PNP, p_samples, c["obj"], p_threshold, p_confidence, p_iters,
-                                                     img=c["img"], K=K, n_dev=n_p, workspace=workspace, first_block=first_block)
+                                                     img=c["img"], K=K, n_dev=n_p, workspace=workspace, first_block=first_block_pnp)
         out.p_result, out.pose, out.rvec, out.p_mask = p_res, pose, rvec, p_mask
+        out.p_samples, out.obj, out.img = p_samples, c["obj"], c["img"]
     return out

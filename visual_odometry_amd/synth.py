@@ -85,3 +85,23 @@ def pnp_scene(n: int, K: np.ndarray = K_MALAGA, size=(1024, 768), seed: int = 43
     """-> dict(R, t (world->camera), obj (n,3) f32 world points, img (n,2) f32 pixels, inlier)."""
     s = two_view_scene(n, K, size, seed, noise_px, outlier_frac, max_rot_deg)
     return dict(R=s["R"], t=s["t"], obj=s["X"].astype(np.float32), img=s["p2"], inlier=s["inlier"], K=K)
+
+
+def frame_pair(nq: int, nt: int, seed: int = 0, K: np.ndarray = K_MALAGA, size=(1024, 768), match_frac: float = 0.6,
+               desc_noise: float = 8.0, noise_px: float = 0.3):
+    """Two synthetic frames as SIFT would describe them, with geometry behind the true matches:
+    -> dict(q, t (n,128) f32 descriptors; kp_q (nq,2), kp_t (nt,2) f32 positions; xyz_q (nq,3) f32
+    landmarks of the query keypoints in the query camera frame; R, t the relative pose; K).
+    ~match_frac of the train features are noisy copies of query features placed at the projection of
+    the query's landmark; the rest is clutter at random positions."""
+    rng = np.random.default_rng(seed)
+    sc = two_view_scene(nq, K=K, size=size, seed=seed, noise_px=noise_px, outlier_frac=0.0)
+    q = sift_like(nq, rng)
+    t = sift_like(nt, rng)
+    nmatch = int(match_frac * min(nq, nt))
+    src, dst = rng.permutation(nq)[:nmatch], rng.permutation(nt)[:nmatch]
+    t[dst] = np.clip(np.rint(q[src] + rng.normal(0.0, desc_noise, (nmatch, 128))), 0, 255).astype(np.float32)
+    kp_t = np.stack([rng.uniform(0, size[0], nt), rng.uniform(0, size[1], nt)], axis=1).astype(np.float32)
+    kp_t[dst] = sc["p2"][src]
+    return dict(q=q, t=t, kp_q=sc["p1"].astype(np.float32), kp_t=kp_t, xyz_q=sc["X"].astype(np.float32),
+                R=sc["R"], t_vec=sc["t"], K=K)
