@@ -1,0 +1,61 @@
+// f64 VALU issue-rate microbenchmark for gfx950 (not product code): cycles per wave64 instruction per
+// SIMD for v_fma_f64 / v_mul_f64 / v_add_f64 / v_cmp_f64 at 1..8 waves per SIMD.
+//   hipcc --offload-arch=gfx950 -O3 -o f64rates scripts/ubench/f64rates.hip && ./f64rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+template <int OP>
+__global__ __launch_bounds__(256) void k(double* out, int iters, double seed)
+{
+    double a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = seed + threadIdx.x * 1e-3 + i;
+    const double m = 1.0000001, c = 1e-9;
+    int cnt = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (OP == 0) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+                if (OP == 1) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                if (OP == 2) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                if (OP == 3) asm volatile("v_cmp_lt_f64 vcc, %0, %1" : : "v"(a[i]), "v"(m) : "vcc");
+                if (OP == 4) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(*(float*)&a[i]) : "v"((float)m), "v"((float)c));
+            }
+        }
+    }
+    double s = cnt;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += a[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int OP>
+void run(const char* name, int wg_per_cu)
+{
+    int cus = 256;
+    double* out;
+    hipMalloc(&out, sizeof(double) * 256 * cus * wg_per_cu);
+    const int iters = 20000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<OP>, dim3(cus * wg_per_cu), dim3(256), 0, 0, out, 100, 1.0);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<OP>, dim3(cus * wg_per_cu), dim3(256), 0, 0, out, iters, 1.0);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double instr_per_simd = (double)iters * 64 * wg_per_cu;   // 4 waves per WG = 1 per SIMD
+    printf("%-12s waves/SIMD %d: %.2f ns per instr per SIMD = %.2f cycles @2.4GHz\n", name, wg_per_cu,
+           ms * 1e6 / instr_per_simd, ms * 1e6 / instr_per_simd * 2.4);
+    hipFree(out);
+}
+
+int main()
+{
+    for (int w : {1, 2, 4, 8}) {
+        run<0>("v_fma_f64", w); run<1>("v_mul_f64", w); run<2>("v_add_f64", w); run<3>("v_cmp_lt_f64", w); run<4>("v_fma_f32", w);
+    }
+    return 0;
+}

@@ -53,6 +53,55 @@ def test_score_fund_threshold_edge(oracle_mod, dev, fund_models):
         assert cnt[0] == int((err <= t2).sum())
 
 
+def test_score_fund_filter_at_every_boundary(oracle_mod, dev, fund_models):
+    """The count kernel decides most correspondences with a division-free filter and falls back to the
+    exact evaluation near the threshold: put the threshold ON the error of many different points (and
+    one f32 ulp either side) for the best and for a mediocre model."""
+    sc, p1, p2, models = fund_models
+    pts4 = np.concatenate([p1, p2], 1).astype(np.float32)
+    counts = np.array([oracle_mod.find_inliers(oracle_mod.fund_error(m, p1, p2), 1.0)[0] for m in models])
+    checked = 0
+    for m in (models[int(np.argmax(counts))], models[len(models) // 2]):
+        err = oracle_mod.fund_error(m, p1, p2)
+        for e in np.sort(err)[5:1500:37]:
+            for t2 in (e, np.nextafter(e, np.float32(0)), np.nextafter(e, np.float32(np.inf))):
+                thr = float(np.sqrt(np.float64(t2)))
+                if np.float32(thr * thr) != t2:
+                    continue
+                cnt = ops.score_fund(_d(m[None], dev), _d(pts4, dev), thr).cpu().numpy()
+                assert cnt[0] == int((err <= t2).sum())
+                checked += 1
+    assert checked > 40
+
+
+def test_score_fund_filter_degenerate_and_scaled(oracle_mod, dev, fund_models):
+    """Zero / NaN / Inf / denormal-scale models and far-away or non-finite points: the filter must hand
+    every such case to the exact evaluation (same counts as the scalar definition)."""
+    sc, p1, p2, models = fund_models
+    rng = np.random.default_rng(5)
+    base = models[:24].copy()
+    extra = [np.zeros(9), np.full(9, np.nan), np.full(9, np.inf)]
+    for k in range(9):
+        m = base[k].copy(); m[k] = np.nan; extra.append(m)
+        m = base[k].copy(); m[k] = np.inf; extra.append(m)
+        m = base[k].copy(); m[k] = 0.0; extra.append(m)
+    m = np.zeros(9); m[8] = 1.0; extra.append(m)                      # a = b = 0: zero denominators
+    m = np.zeros(9); m[2] = 1.0; m[6] = -1.0; extra.append(m)
+    scaled = [base[i] * s for i, s in enumerate([1e-300, 1e-160, 1e-150, 1e-100, 1e100, 1e150, 1e160, 1e300])]
+    mods = np.concatenate([base, np.array(extra), np.array(scaled)])
+    for scale, poison in ((1.0, False), (1.0, True), (1e4, False), (1e-3, False)):
+        q1 = (p1[:700].astype(np.float64) * scale).astype(np.float32)
+        q2 = (p2[:700].astype(np.float64) * scale).astype(np.float32)
+        if poison:
+            q1[3, 0] = np.nan; q2[10, 1] = np.inf; q1[20] = 0; q2[20] = 0; q1[21, 0] = 3e38
+        pts4 = np.concatenate([q1, q2], 1).astype(np.float32)
+        for thr in (0.1 * scale, 2.0 * scale):
+            with np.errstate(all="ignore"):
+                ref = np.array([oracle_mod.find_inliers(oracle_mod.fund_error(m, q1, q2), thr)[0] for m in mods])
+            cnt = ops.score_fund(_d(mods, dev), _d(pts4, dev), thr).cpu().numpy()
+            assert np.array_equal(cnt, ref), (scale, poison, thr, np.nonzero(cnt != ref)[0][:10])
+
+
 def test_score_valid_flags_and_empty(dev, fund_models):
     sc, p1, p2, models = fund_models
     pts4 = np.concatenate([p1, p2], 1).astype(np.float32)

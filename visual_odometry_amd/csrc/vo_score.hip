@@ -16,6 +16,16 @@
 // atomics, which are order-independent.
 #include "vo_common.h"
 
+#ifndef VO_SCORE_G
+#define VO_SCORE_G 2                  // correspondences per filter group of the F count kernel
+#endif
+#ifndef VO_SCORE_MINW
+#define VO_SCORE_MINW 1               // launch-bounds hint: waves per SIMD the register budget must allow
+#endif
+#ifndef VO_SCORE_ABLATE
+#define VO_SCORE_ABLATE 0             // scripts/score_ablate.sh: 1 = filter only, never the exact path
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -39,6 +49,68 @@ __device__ __forceinline__ float fund_err(const double* F, double x1, double y1,
     d1 = x1 * a + y1 * b + c;
     const double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
     return (float)(e1 < e2 ? e2 : e1);
+}
+
+// Sure-inlier / sure-outlier filter for fund_err, used by the count kernel only.  The verdict
+// "(float)max(e1,e2) <= thr2" needs two correctly rounded divides per correspondence; they decide
+// nothing unless d^2 and thr2*den are within rounding distance of each other.  The filter evaluates
+// the two residuals with fused multiply-adds (any evaluation order is fine here) and returns
+//   +1  both residuals are below the threshold by more than every rounding error that can separate
+//       this evaluation from fund_err's,
+//   -1  one residual is above it by more than that,
+//    0  cannot tell (includes every NaN/Inf/zero-denominator case): the caller runs fund_err.
+// Error budget (eps = 2^-53; Q1 >= max(|x1|,|y1|,1) and Q2 likewise over the staged chunk; q = (Q,Q,1)):
+//   S  = sum_ij |F_ij| q2_i q1_j bounds every partial sum of x2^T F x1, so the two evaluations of d
+//        differ by <= 12 eps S                                   (eta carries 2^-44 S);
+//   al = max row (column) sum of |F| weighted by q bounds the same for a and b: <= 6 eps al apart
+//        (alpha carries 2^-46 al), hence den by <= 2(|a|+|b|) alpha + 2 alpha^2 + 4 eps den
+//        <= 2^-21 den + (2^22+2) alpha^2   (AM-GM with (|a|+|b|)^2 <= 2 den);
+//   the divide, the product and the f32 cast of the exact path move e by < 2^-22 relative.
+// With z = d^2 - thr2 den and
+//   m = 2 eta |d| + 2^-19 thr2 den + 2 (eta^2 + 2^24 thr2 alpha^2) + 2^-600:
+//   z < -m  =>  (|d|+eta)^2 <= thr2 (1-2^-20)(den-dlt)   and   z > m  =>  (|d|-eta)^2 >= thr2 (1+2^-20)(den+dlt).
+// A NaN anywhere makes both compares false; an Inf makes m Inf or NaN: both end in "cannot tell".
+struct FundFilter {
+    double t, rel, eta2, c1, c2;       // thr2, 2^-19 thr2, 2 eta, constant terms of m for den1 / den2
+};
+
+__device__ __forceinline__ FundFilter fund_filter_setup(const double* F, double thr2, double Q1, double Q2)
+{
+    double A[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) A[k] = fabs(F[k]);
+    const double S = (A[0] + A[1] + A[3] + A[4]) * Q2 * Q1 + (A[2] + A[5]) * Q2 + (A[6] + A[7]) * Q1 + A[8];
+    const double eta = 0x1p-44 * S;
+    // den2 = a^2+b^2 of F x1 (rows 0,1 of F); den1 of F^T x2 (columns 0,1 of F)
+    const double al2 = 0x1p-46 * fmax((A[0] + A[1]) * Q1 + A[2], (A[3] + A[4]) * Q1 + A[5]);
+    const double al1 = 0x1p-46 * fmax((A[0] + A[3]) * Q2 + A[6], (A[1] + A[4]) * Q2 + A[7]);
+    FundFilter f;
+    f.t = thr2;
+    f.rel = 0x1p-19 * thr2;
+    f.eta2 = 2. * eta;
+    f.c1 = 2. * (eta * eta + 0x1p24 * thr2 * al1 * al1) + 0x1p-600;
+    f.c2 = 2. * (eta * eta + 0x1p24 * thr2 * al2 * al2) + 0x1p-600;
+    return f;
+}
+
+__device__ __forceinline__ int fund_filter(const double* F, const FundFilter& f, double x1, double y1, double x2, double y2)
+{
+    const double a1 = __builtin_fma(F[0], x1, __builtin_fma(F[1], y1, F[2]));
+    const double b1 = __builtin_fma(F[3], x1, __builtin_fma(F[4], y1, F[5]));
+    const double c1 = __builtin_fma(F[6], x1, __builtin_fma(F[7], y1, F[8]));
+    const double den2 = __builtin_fma(a1, a1, b1 * b1);
+    const double d2 = __builtin_fma(x2, a1, __builtin_fma(y2, b1, c1));
+    const double a2 = __builtin_fma(F[0], x2, __builtin_fma(F[3], y2, F[6]));
+    const double b2 = __builtin_fma(F[1], x2, __builtin_fma(F[4], y2, F[7]));
+    const double c2 = __builtin_fma(F[2], x2, __builtin_fma(F[5], y2, F[8]));
+    const double den1 = __builtin_fma(a2, a2, b2 * b2);
+    const double d1 = __builtin_fma(x1, a2, __builtin_fma(y1, b2, c2));
+    const double z1 = __builtin_fma(-f.t, den1, d1 * d1), z2 = __builtin_fma(-f.t, den2, d2 * d2);
+    const double m1 = __builtin_fma(f.eta2, fabs(d1), __builtin_fma(f.rel, den1, f.c1));
+    const double m2 = __builtin_fma(f.eta2, fabs(d2), __builtin_fma(f.rel, den2, f.c2));
+    if ((z1 < -m1) & (z2 < -m2)) return 1;
+    if ((z1 > m1) | (z2 > m2)) return -1;
+    return 0;
 }
 
 // EMEstimatorCallback::computeError: Sampson distance on normalised coordinates
@@ -104,7 +176,7 @@ struct ScoreArgs {
 };
 
 template <int KIND>
-__global__ __launch_bounds__(kThreads)
+__global__ __launch_bounds__(kThreads, VO_SCORE_MINW)
 void score_kernel(const ScoreArgs a)
 {
     constexpr int MW = KIND == kPnp ? 12 : 9;
@@ -117,12 +189,23 @@ void score_kernel(const ScoreArgs a)
     if (p0 >= n || (int)(blockIdx.x * kThreads) >= nslots) return;      // block-uniform
     const int np = min(a.chunk, n - p0);
 
+    __shared__ double sscale[2][kThreads / 64];
     if (KIND == kFund) {
         const float4* pts = (const float4*)a.pts + (size_t)b * a.N + p0;
+        double p1 = 1., p2 = 1.;                   // chunk-wide bounds on max(|x|,|y|,1) of either image
         for (int i = threadIdx.x; i < np; i += kThreads) {
             const float4 v = pts[i];
             sp[4 * i] = v.x; sp[4 * i + 1] = v.y; sp[4 * i + 2] = v.z; sp[4 * i + 3] = v.w;
+            const double q1 = fmax(fabs((double)v.x), fabs((double)v.y)), q2 = fmax(fabs((double)v.z), fabs((double)v.w));
+            p1 = fmax(p1, q1);                     // a NaN point fails the filter by itself
+            p2 = fmax(p2, q2);
         }
+        for (int o = 32; o; o >>= 1) {
+            const double o1 = __shfl_xor(p1, o), o2 = __shfl_xor(p2, o);
+            p1 = fmax(p1, o1);
+            p2 = fmax(p2, o2);
+        }
+        if ((threadIdx.x & 63) == 0) { sscale[0][threadIdx.x >> 6] = p1; sscale[1][threadIdx.x >> 6] = p2; }
     } else if (KIND == kEss) {
         const double* pts = (const double*)a.pts + ((size_t)b * a.N + p0) * 4;
         for (int i = threadIdx.x; i < np * 4; i += kThreads) sp[i] = pts[i];
@@ -145,25 +228,73 @@ void score_kernel(const ScoreArgs a)
 #pragma unroll
     for (int k = 0; k < MW; ++k) M[k] = live ? a.models[gslot * MW + k] : 0.;
     __syncthreads();
+    if (!__any(live)) return;                  // wave past the end of the model list (no barrier follows)
     int cnt = 0;
-    auto one = [&](int i) {
-        const double2 u = *(const double2*)(sp + 4 * i);
-        if (KIND == kPnp) {
-            const double Z = sp[4 * i + 2];
-            const float2 uv = *(const float2*)(sp + 4 * i + 3);
-            cnt += pnp_err(M, a.fx, a.fy, a.cx, a.cy, u.x, u.y, Z, uv.x, uv.y) <= a.thr2;
-        } else {
-            const double2 v = *(const double2*)(sp + 4 * i + 2);
-            cnt += (KIND == kFund ? fund_err(M, u.x, u.y, v.x, v.y) : sampson_err(M, u.x, u.y, v.x, v.y)) <= a.thr2;
+    FundFilter ff;
+    if (KIND == kFund) {
+        double p1 = sscale[0][0], p2 = sscale[1][0];
+#pragma unroll
+        for (int w = 1; w < kThreads / 64; ++w) {
+            const double o1 = sscale[0][w], o2 = sscale[1][w];
+            p1 = fmax(p1, o1);
+            p2 = fmax(p2, o2);
         }
-    };
-    // four correspondences per trip: the loop bookkeeping (and the LDS wait) is paid once per four
-    // error evaluations; each evaluation itself is unchanged
-    int i = 0;
-    for (; i + 4 <= np; i += 4) {
-        one(i); one(i + 1); one(i + 2); one(i + 3);
+        ff = fund_filter_setup(M, (double)a.thr2, p1, p2);
     }
-    for (; i < np; ++i) one(i);
+    if (KIND == kFund) {
+        // Groups of eight correspondences: fast verdicts for the whole wave; if any lane met a
+        // "cannot tell" (within rounding distance of the threshold, or degenerate), the group is
+        // re-evaluated exactly by the whole wave.  One wave-uniform branch per group keeps the
+        // common path a straight run of f64 FMAs.
+        constexpr int G = VO_SCORE_G;
+        auto exact = [&](int i) {
+            const double2 u = *(const double2*)(sp + 4 * i), v = *(const double2*)(sp + 4 * i + 2);
+            return (int)(fund_err(M, u.x, u.y, v.x, v.y) <= a.thr2);
+        };
+        int i = 0;
+        for (; i + G <= np; i += G) {
+            int c = 0;
+            bool amb = false;
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const double2 u = *(const double2*)(sp + 4 * (i + k)), v = *(const double2*)(sp + 4 * (i + k) + 2);
+                const int verdict = fund_filter(M, ff, u.x, u.y, v.x, v.y);
+                c += verdict > 0;
+                amb |= live & (verdict == 0);      // a lane without a model (all-zero M) never asks
+            }
+#if VO_SCORE_ABLATE == 2               // diagnostic: count the groups that fall back (own / wave)
+            if (__any(amb)) c = (1 << 12) + (amb ? 1 << 22 : 0);
+#elif VO_SCORE_ABLATE != 1             // 1: timing experiment only (wrong near the threshold)
+            if (__any(amb)) {
+                c = 0;
+#pragma unroll 1
+                for (int k = 0; k < G; ++k) c += exact(i + k);
+            }
+#endif
+            cnt += c;
+        }
+#pragma unroll 1
+        for (; i < np; ++i) cnt += exact(i);
+    } else {
+        auto one = [&](int i) {
+            const double2 u = *(const double2*)(sp + 4 * i);
+            if (KIND == kPnp) {
+                const double Z = sp[4 * i + 2];
+                const float2 uv = *(const float2*)(sp + 4 * i + 3);
+                cnt += pnp_err(M, a.fx, a.fy, a.cx, a.cy, u.x, u.y, Z, uv.x, uv.y) <= a.thr2;
+            } else {
+                const double2 v = *(const double2*)(sp + 4 * i + 2);
+                cnt += sampson_err(M, u.x, u.y, v.x, v.y) <= a.thr2;
+            }
+        };
+        // four correspondences per trip: the loop bookkeeping (and the LDS wait) is paid once per four
+        // error evaluations; each evaluation itself is unchanged
+        int i = 0;
+        for (; i + 4 <= np; i += 4) {
+            one(i); one(i + 1); one(i + 2); one(i + 3);
+        }
+        for (; i < np; ++i) one(i);
+    }
     if (live && cnt) atomicAdd(a.counts + gslot, cnt);
 }
 
