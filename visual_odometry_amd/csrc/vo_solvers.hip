@@ -22,12 +22,32 @@ constexpr double kPi = 3.1415926535897932384626433832795;
 // Compacted list of the model slots that hold a model, per problem: the scoring kernel then
 // spends no lanes on the empty slots of samples with fewer than `width` solutions.  The order of
 // the list depends on atomic arrival order; nothing downstream depends on it (counts land in
-// their slot).
+// their slot).  Called by every lane of the wave (n = 0 for lanes without a sample).  The
+// per-problem counters of a batch share one or two cache lines, i.e. one or two L2 channels, so one
+// atomic per lane serialises the whole launch there: a wave whose lanes all belong to one problem
+// (the normal case) reserves its range with a single atomic instead.
 __device__ __forceinline__ void append_slots(int32_t* list, int32_t* nlist, int b, int local_h, int per,
                                              int width, int n)
 {
-    if (!list || n <= 0) return;
-    const int base = atomicAdd(nlist + b, n);
+    if (!list) return;                                   // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const int b0 = __shfl(b, __ffsll((long long)__ballot(n > 0)) - 1);
+    int base;
+    if (__all(n <= 0 || b == b0)) {
+        int incl = n;                                    // inclusive scan of n over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        const int total = __shfl(incl, 63);
+        if (total == 0) return;
+        int start = 0;
+        if (lane == 0) start = atomicAdd(nlist + b0, total);
+        base = __shfl(start, 0) + incl - n;
+    } else {
+        base = n > 0 ? atomicAdd(nlist + b, n) : 0;
+    }
     for (int k = 0; k < n; ++k) list[(size_t)b * per * width + base + k] = local_h * width + k;
 }
 
@@ -139,6 +159,146 @@ __device__ void jacobi_svd(SV At, int m, int n, int n1, SV W, SV Vt)
     }
 }
 
+// The same algorithm (no V) on a matrix held in registers: every loop over rows and elements is
+// unrolled so that all indices are compile-time constants; data-dependent control flow (rotation
+// skipped, convergence, degenerate rows) is per-lane predication.  Operation order is that of
+// jacobi_svd above, element for element, so both produce the same bits.  A lane that has converged
+// rides along with the sweeps other lanes still need: with nothing left to rotate they change nothing.
+template <int M, int N, int N1>
+__device__ __forceinline__ void jacobi_rows_reg(double (&A)[N1][M], double (&W)[N1])
+{
+    const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
+    constexpr int max_iter = M > 30 ? M : 30;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < M; ++k) sd += A[i][k] * A[i][k];
+        W[i] = sd;
+    }
+    // Pair order is OpenCV's: (0,1) (0,2) .. (0,N-1) (1,2) ..  To keep the sweep small enough for the
+    // instruction cache only the pairs (0,j) exist as code; after row i has met all its partners the
+    // rows are rotated up by one (register moves), so the next pivot row sits in slot 0 again and the
+    // rows already done wrap to the end, where the shrinking partner count leaves them alone.  N
+    // rotations restore the order.
+#pragma unroll 1
+    for (int iter = 0; iter < max_iter; ++iter) {
+        bool changed = false;
+#pragma unroll 1
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+            for (int j = 1; j < N; ++j) {
+                if (j > N - 1 - i) continue;               // wave-uniform
+                double a = W[0], p = 0, b = W[j];
+#pragma unroll
+                for (int k = 0; k < M; ++k) p += A[0][k] * A[j][k];
+                if (!(fabs(p) <= eps * sqrt(a * b))) {
+                    p *= 2;
+                    const double beta = a - b, gamma = sqrt(p * p + beta * beta);
+                    double c, s;
+                    if (beta < 0) {
+                        const double delta = (gamma - beta) * 0.5;
+                        s = sqrt(delta / gamma);
+                        c = p / (gamma * s * 2);
+                    } else {
+                        c = sqrt((gamma + beta) / (gamma * 2));
+                        s = p / (gamma * c * 2);
+                    }
+                    a = b = 0;
+#pragma unroll
+                    for (int k = 0; k < M; ++k) {
+                        const double t0 = c * A[0][k] + s * A[j][k];
+                        const double t1 = -s * A[0][k] + c * A[j][k];
+                        A[0][k] = t0; A[j][k] = t1;
+                        a += t0 * t0; b += t1 * t1;
+                    }
+                    W[0] = a; W[j] = b;
+                    changed = true;
+                }
+            }
+            const double w0 = W[0];
+#pragma unroll
+            for (int r = 0; r < N - 1; ++r) W[r] = W[r + 1];
+            W[N - 1] = w0;
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+                const double t = A[0][k];
+#pragma unroll
+                for (int r = 0; r < N - 1; ++r) A[r][k] = A[r + 1][k];
+                A[N - 1][k] = t;
+            }
+        }
+        if (!__any(changed)) break;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < M; ++k) sd += A[i][k] * A[i][k];
+        W[i] = sqrt(sd);
+    }
+    // selection sort, descending: row i <-> the first largest of rows i..N-1
+#pragma unroll
+    for (int i = 0; i < N - 1; ++i) {
+        int j = i;
+        double wj = W[i];
+#pragma unroll
+        for (int k = i + 1; k < N; ++k)
+            if (wj < W[k]) { j = k; wj = W[k]; }
+#pragma unroll
+        for (int k = i + 1; k < N; ++k)
+            if (j == k) {
+                double t = W[i]; W[i] = W[k]; W[k] = t;
+#pragma unroll
+                for (int e = 0; e < M; ++e) { t = A[i][e]; A[i][e] = A[k][e]; A[k][e] = t; }
+            }
+    }
+    unsigned long long rs = 0x12345678ULL;
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+        double sd = i < N ? W[i] : 0;
+#pragma unroll 1
+        for (int ii = 0; ii < 100 && __any(sd <= minval); ++ii) {
+            // the +-1/M pattern is the same for every lane; lanes whose row is fine keep theirs, but
+            // must draw exactly as many numbers as a scalar run would: none.  A lane that is not
+            // degenerate here never consumes from rs, so rs has to be per lane.
+            if (sd <= minval) {
+                const double val0 = 1. / M;
+#pragma unroll
+                for (int k = 0; k < M; ++k) {
+                    rs = (unsigned long long)(unsigned)rs * 4164903690u + (unsigned)(rs >> 32);
+                    A[i][k] = ((unsigned)rs & 256) != 0 ? val0 : -val0;
+                }
+#pragma unroll 1
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int j = 0; j < i; ++j) {
+                        double d = 0;
+#pragma unroll
+                        for (int k = 0; k < M; ++k) d += A[i][k] * A[j][k];
+                        double asum = 0;
+#pragma unroll
+                        for (int k = 0; k < M; ++k) {
+                            const double t = A[i][k] - d * A[j][k];
+                            A[i][k] = t;
+                            asum += fabs(t);
+                        }
+                        asum = asum > eps * 100 ? 1 / asum : 0;
+#pragma unroll
+                        for (int k = 0; k < M; ++k) A[i][k] *= asum;
+                    }
+                double q = 0;
+#pragma unroll
+                for (int k = 0; k < M; ++k) q += A[i][k] * A[i][k];
+                sd = sqrt(q);
+            }
+        }
+        const double sc = sd > minval ? 1 / sd : 0.;
+#pragma unroll
+        for (int k = 0; k < M; ++k) A[i][k] *= sc;
+    }
+}
+
 // a0 x^3 + a1 x^2 + a2 x + a3 = 0 (Cardano / trigonometric form).  returns #real roots
 __device__ int solve_cubic(double a0, double a1, double a2, double a3, double* r)
 {
@@ -197,7 +357,6 @@ void solve_7pt_kernel(const int32_t* __restrict__ samples, int H, const float4* 
                       int per, int32_t* __restrict__ list, int32_t* __restrict__ nlist, const int32_t* __restrict__ n_dev,
                       int h0, int hlen, const int32_t* __restrict__ prev)
 {
-    __shared__ double lds[(81 + 9) * kLanes];
     // thread -> (problem b, iteration h0 + i) for the iteration block [h0, h0 + hlen) of every problem;
     // a problem whose sequential loop already ended (prev = its replay result, niters <= h0) is skipped
     const int tix = blockIdx.x * kLanes + threadIdx.x;
@@ -209,23 +368,29 @@ void solve_7pt_kernel(const int32_t* __restrict__ samples, int H, const float4* 
     if (!__any(live)) return;                 // problem this sample belongs to
     const int nb_pts = n_dev ? min(n_dev[b], N) : N;
     pts += (size_t)b * N;
-    const SV A{lds + threadIdx.x}, W{lds + 81 * kLanes + threadIdx.x};
-    for (int k = 0; k < 81; ++k) A[k] = 0;
+    // the 7 x 9 epipolar constraint rows and, after the SVD, the two null-space rows: all in VGPRs
+    double A[9][9], W[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        W[i] = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) A[i][k] = 0;
+    }
+#pragma unroll
     for (int i = 0; i < 7; ++i) {
         int idx = live ? samples[(size_t)h * 7 + i] : 0;
         idx = max(min(idx, nb_pts - 1), 0);
         const float4 p = pts[idx];
         const double x0 = p.x, y0 = p.y, x1 = p.z, y1 = p.w;
-        const SV r = A.at(i * 9);
-        r[0] = x1 * x0; r[1] = x1 * y0; r[2] = x1;
-        r[3] = y1 * x0; r[4] = y1 * y0; r[5] = y1;
-        r[6] = x0; r[7] = y0; r[8] = 1;
+        A[i][0] = x1 * x0; A[i][1] = x1 * y0; A[i][2] = x1;
+        A[i][3] = y1 * x0; A[i][4] = y1 * y0; A[i][5] = y1;
+        A[i][6] = x0; A[i][7] = y0; A[i][8] = 1;
     }
-    jacobi_svd<false>(A, 9, 7, 9, W, SV{nullptr});
+    jacobi_rows_reg<9, 7, 9>(A, W);
 
     double f1[9], f2[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { f2[i] = A[8 * 9 + i]; f1[i] = A[7 * 9 + i] - f2[i]; }
+    for (int i = 0; i < 9; ++i) { f2[i] = A[8][i]; f1[i] = A[7][i] - f2[i]; }
     double c[4], r[3];
     double t0, t1, t2;
     t0 = f2[4] * f2[8] - f2[5] * f2[7];
@@ -252,9 +417,9 @@ void solve_7pt_kernel(const int32_t* __restrict__ samples, int H, const float4* 
            f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
     int n = solve_cubic(c[0], c[1], c[2], c[3], r);
     if (n < 1 || n > 3) n = 0;
+    append_slots(list, nlist, b, h - b * per, per, 3, live ? n : 0);
     if (!live) return;
     nmodels[h] = n;
-    append_slots(list, nlist, b, h - b * per, per, 3, n);
     for (int k = 0; k < n; ++k) {
         double* F = models + ((size_t)h * 3 + k) * 9;
         double lambda = r[k], mu = 1.;
@@ -729,9 +894,9 @@ void solve_p3p_kernel(const int32_t* __restrict__ samples, int H, const float* _
         for (int j = i; j > 0 && e4[pos[j - 1]] > e4[pos[j]]; --j) {
             const int tmp = pos[j]; pos[j] = pos[j - 1]; pos[j - 1] = tmp;
         }
+    append_slots(list, nlist, b, h - b * per, per, 1, live && nb > 0 ? 1 : 0);
     if (!live) return;
     nmodels[h] = nb > 0 ? 1 : 0;
-    append_slots(list, nlist, b, h - b * per, per, 1, nb > 0 ? 1 : 0);
     if (nb > 0) {
         const int o = order[pos[0]];
 #pragma unroll
@@ -972,10 +1137,8 @@ void solve_5pt_kernel(const int32_t* __restrict__ samples, int H, const double* 
             count++;
         }
     }
-    if (live) {
-        nmodels[h] = count;
-        append_slots(list, nlist, b, h - b * per, per, 10, count);
-    }
+    append_slots(list, nlist, b, h - b * per, per, 10, live ? count : 0);
+    if (live) nmodels[h] = count;
 }
 
 }  // namespace
