@@ -3,7 +3,7 @@
 # kernel time differs.   bash scripts/score_variants.sh build   |   bash scripts/score_variants.sh run
 set -e
 cd "$(dirname "$0")/.."
-VARS="1_1 2_2 3_1 2_1"
+VARS="1_1 2_1 4_1 8_1 4_2 8_2"
 if [ "$1" = build ]; then
   mkdir -p ablate/vobj
   for f in vo_runtime vo_knn vo_ransac vo_solvers vo_epnp vo_pipeline; do

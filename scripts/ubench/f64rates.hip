@@ -22,6 +22,10 @@ __global__ __launch_bounds__(256) void k(double* out, int iters, double seed)
                 if (OP == 2) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a[i]) : "v"(c));
                 if (OP == 3) asm volatile("v_cmp_lt_f64 vcc, %0, %1" : : "v"(a[i]), "v"(m) : "vcc");
                 if (OP == 4) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(*(float*)&a[i]) : "v"((float)m), "v"((float)c));
+                if (OP == 5) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+                if (OP == 6) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                if (OP == 7) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(*(float*)&a[i]), "v"((float)m) : "vcc");
+                if (OP == 8) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(*(float*)&a[i]) : "v"((float)m));
             }
         }
     }
@@ -54,8 +58,8 @@ void run(const char* name, int wg_per_cu)
 
 int main()
 {
-    for (int w : {1, 2, 4, 8}) {
-        run<0>("v_fma_f64", w); run<1>("v_mul_f64", w); run<2>("v_add_f64", w); run<3>("v_cmp_lt_f64", w); run<4>("v_fma_f32", w);
+    for (int w : {2, 8}) {
+        run<0>("v_fma_f64", w); run<1>("v_mul_f64", w); run<2>("v_add_f64", w); run<3>("v_cmp_lt_f64", w); run<4>("v_fma_f32", w); run<5>("v_pk_fma_f32", w); run<6>("v_pk_mul_f32", w); run<7>("v_cmp_lt_f32", w); run<8>("v_mul_f32", w);
     }
     return 0;
 }

@@ -17,7 +17,7 @@
 #include "vo_common.h"
 
 #ifndef VO_SCORE_G
-#define VO_SCORE_G 2                  // correspondences per filter group of the F count kernel
+#define VO_SCORE_G 4                  // unroll factor of the tier-1 loop of the F count kernel
 #endif
 #ifndef VO_SCORE_MINW
 #define VO_SCORE_MINW 1               // launch-bounds hint: waves per SIMD the register budget must allow
@@ -113,6 +113,81 @@ __device__ __forceinline__ int fund_filter(const double* F, const FundFilter& f,
     return 0;
 }
 
+// First stage of the same filter in f32 (wave64 f32 FMAs issue ~1.7x faster than f64 ones on
+// gfx950 and the verdict of most correspondences is nowhere near the threshold).  The model is
+// scaled by a power of two so that max|F_k| lies in [0.5,1) (the verdict is scale invariant and the
+// scaling is exact), which keeps every quantity that matters far from f32 underflow, then rounded
+// to f32.  Budget with u = 2^-24: model rounding + two FMAs put a,b,c within 3u of their partial-sum
+// bound, d within 5u S (eta carries 2^-20 S), den within 2(|a|+|b|) alpha + 2 alpha^2 + 2u den with
+// alpha = 2^-21 al  =>  <= 2^-19 den + 2^21 alpha^2 by AM-GM; z and m themselves are rounded to f32
+// (<= 2^-22 relative of d^2 + thr2 den); the exact path's own roundings are < 2^-22.  All of it is
+// covered, with at least 2x to spare per term, by
+//   m = 2 eta |d| + 2^-17 thr2 den + 2 (eta^2 + 2^22 thr2 alpha^2).
+// A model that is zero, NaN, Inf or scaled beyond 2^+-300 gets eta = Inf: every verdict is "cannot tell".
+struct FundFilter32 {
+    float F[9];
+    float t, rel, eta2, c1, c2;
+};
+
+__device__ __forceinline__ FundFilter32 fund_filter32_setup(const double* F, float thr2, double Q1, double Q2)
+{
+    FundFilter32 f;
+    double fm = 0.;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) fm = fmax(fm, fabs(F[k]));
+    double nanprobe = 0.;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) nanprobe += F[k] * 0.;           // NaN if any entry is NaN or Inf
+    // The rescaled f32 evaluation cannot see the underflow/overflow the exact f64 evaluation runs into
+    // for absurdly scaled models or thresholds; inside this window a sure verdict here (which needs
+    // max(d^2, thr2 den) > 2^-41 in scaled units) keeps every exact-path quantity that decides in
+    // the normal range.
+    const bool usable = fm > 0x1p-300 && fm < 0x1p300 && thr2 >= 0x1p-100f && thr2 <= 0x1p100f && nanprobe == 0.;
+    int e = 0;
+    (void)frexp(usable ? fm : 1., &e);
+    const double sigma = ldexp(1., -e);                          // fm * sigma in [0.5, 1)
+    double A[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const double g = F[k] * sigma;
+        f.F[k] = (float)g;
+        A[k] = fabs(g);
+    }
+    const double S = (A[0] + A[1] + A[3] + A[4]) * Q2 * Q1 + (A[2] + A[5]) * Q2 + (A[6] + A[7]) * Q1 + A[8];
+    const double eta = 0x1p-20 * S;
+    const double al2 = 0x1p-21 * fmax((A[0] + A[1]) * Q1 + A[2], (A[3] + A[4]) * Q1 + A[5]);
+    const double al1 = 0x1p-21 * fmax((A[0] + A[3]) * Q2 + A[6], (A[1] + A[4]) * Q2 + A[7]);
+    const double up = 1. + 0x1p-20;                              // constants are rounded to f32: round up
+    const float inf = __builtin_huge_valf();
+    f.t = thr2;
+    f.rel = (float)(0x1p-17 * (double)thr2 * up);
+    f.eta2 = usable ? (float)(2. * eta * up) : inf;
+    f.c1 = usable ? (float)(2. * (eta * eta + 0x1p22 * (double)thr2 * al1 * al1) * up) : inf;
+    f.c2 = usable ? (float)(2. * (eta * eta + 0x1p22 * (double)thr2 * al2 * al2) * up) : inf;
+    return f;
+}
+
+__device__ __forceinline__ int fund_filter32(const FundFilter32& f, float x1, float y1, float x2, float y2)
+{
+    const float* F = f.F;
+    const float a1 = __builtin_fmaf(F[0], x1, __builtin_fmaf(F[1], y1, F[2]));
+    const float b1 = __builtin_fmaf(F[3], x1, __builtin_fmaf(F[4], y1, F[5]));
+    const float c1 = __builtin_fmaf(F[6], x1, __builtin_fmaf(F[7], y1, F[8]));
+    const float den2 = __builtin_fmaf(a1, a1, b1 * b1);
+    const float d2 = __builtin_fmaf(x2, a1, __builtin_fmaf(y2, b1, c1));
+    const float a2 = __builtin_fmaf(F[0], x2, __builtin_fmaf(F[3], y2, F[6]));
+    const float b2 = __builtin_fmaf(F[1], x2, __builtin_fmaf(F[4], y2, F[7]));
+    const float c2 = __builtin_fmaf(F[2], x2, __builtin_fmaf(F[5], y2, F[8]));
+    const float den1 = __builtin_fmaf(a2, a2, b2 * b2);
+    const float d1 = __builtin_fmaf(x1, a2, __builtin_fmaf(y1, b2, c2));
+    const float z1 = __builtin_fmaf(-f.t, den1, d1 * d1), z2 = __builtin_fmaf(-f.t, den2, d2 * d2);
+    const float m1 = __builtin_fmaf(f.eta2, fabsf(d1), __builtin_fmaf(f.rel, den1, f.c1));
+    const float m2 = __builtin_fmaf(f.eta2, fabsf(d2), __builtin_fmaf(f.rel, den2, f.c2));
+    if ((z1 < -m1) & (z2 < -m2)) return 1;
+    if ((z1 > m1) | (z2 > m2)) return -1;
+    return 0;
+}
+
 // EMEstimatorCallback::computeError: Sampson distance on normalised coordinates
 __device__ __forceinline__ float sampson_err(const double* E, double ax, double ay, double bx, double by)
 {
@@ -195,7 +270,7 @@ void score_kernel(const ScoreArgs a)
         double p1 = 1., p2 = 1.;                   // chunk-wide bounds on max(|x|,|y|,1) of either image
         for (int i = threadIdx.x; i < np; i += kThreads) {
             const float4 v = pts[i];
-            sp[4 * i] = v.x; sp[4 * i + 1] = v.y; sp[4 * i + 2] = v.z; sp[4 * i + 3] = v.w;
+            ((float4*)sp)[i] = v;                  // F keeps f32 points: exact in either precision
             const double q1 = fmax(fabs((double)v.x), fabs((double)v.y)), q2 = fmax(fabs((double)v.z), fabs((double)v.w));
             p1 = fmax(p1, q1);                     // a NaN point fails the filter by itself
             p2 = fmax(p2, q2);
@@ -230,7 +305,6 @@ void score_kernel(const ScoreArgs a)
     __syncthreads();
     if (!__any(live)) return;                  // wave past the end of the model list (no barrier follows)
     int cnt = 0;
-    FundFilter ff;
     if (KIND == kFund) {
         double p1 = sscale[0][0], p2 = sscale[1][0];
 #pragma unroll
@@ -239,42 +313,54 @@ void score_kernel(const ScoreArgs a)
             p1 = fmax(p1, o1);
             p2 = fmax(p2, o2);
         }
-        ff = fund_filter_setup(M, (double)a.thr2, p1, p2);
-    }
-    if (KIND == kFund) {
-        // Groups of eight correspondences: fast verdicts for the whole wave; if any lane met a
-        // "cannot tell" (within rounding distance of the threshold, or degenerate), the group is
-        // re-evaluated exactly by the whole wave.  One wave-uniform branch per group keeps the
-        // common path a straight run of f64 FMAs.
-        constexpr int G = VO_SCORE_G;
-        auto exact = [&](int i) {
-            const double2 u = *(const double2*)(sp + 4 * i), v = *(const double2*)(sp + 4 * i + 2);
-            return (int)(fund_err(M, u.x, u.y, v.x, v.y) <= a.thr2);
-        };
-        int i = 0;
-        for (; i + G <= np; i += G) {
-            int c = 0;
-            bool amb = false;
-#pragma unroll
-            for (int k = 0; k < G; ++k) {
-                const double2 u = *(const double2*)(sp + 4 * (i + k)), v = *(const double2*)(sp + 4 * (i + k) + 2);
-                const int verdict = fund_filter(M, ff, u.x, u.y, v.x, v.y);
-                c += verdict > 0;
-                amb |= live & (verdict == 0);      // a lane without a model (all-zero M) never asks
-            }
-#if VO_SCORE_ABLATE == 2               // diagnostic: count the groups that fall back (own / wave)
-            if (__any(amb)) c = (1 << 12) + (amb ? 1 << 22 : 0);
-#elif VO_SCORE_ABLATE != 1             // 1: timing experiment only (wrong near the threshold)
-            if (__any(amb)) {
-                c = 0;
+        const FundFilter ff = fund_filter_setup(M, (double)a.thr2, p1, p2);
+        const FundFilter32 f32 = fund_filter32_setup(M, a.thr2, p1, p2);
+        const float4* spf = (const float4*)sp;
+        // Blocks of 32 correspondences.  Tier 1: the f32 filter for every correspondence, branch-free;
+        // a lane that "cannot tell" only sets a bit.  Tier 2, once per block: while any lane has bits,
+        // each such lane takes one of ITS correspondences through the f64 filter and, if that still
+        // cannot tell (within rounding distance of the threshold, or degenerate), the exact
+        // evaluation.  Lanes wait for each other only for the longest bit list of the block, about
+        // one entry per block on image-like data.  A lane without a model (all-zero M) never asks.
+        for (int i0 = 0; i0 < np; i0 += 32) {
+            const int nb = min(32, np - i0);
+            uint32_t bits = 0;
+            auto tier1 = [&](int k) {
+                const float4 v = spf[i0 + k];
+                const int verdict = fund_filter32(f32, v.x, v.y, v.z, v.w);
+                cnt += verdict > 0;
+                bits = (bits << 1) | (uint32_t)(verdict == 0);
+            };
+            if (nb == 32) {
+#pragma unroll VO_SCORE_G
+                for (int k = 0; k < 32; ++k) tier1(k);
+            } else {
 #pragma unroll 1
-                for (int k = 0; k < G; ++k) c += exact(i + k);
+                for (int k = 0; k < nb; ++k) tier1(k);
             }
+            if (!live) bits = 0;
+#if VO_SCORE_ABLATE == 2               // diagnostic: count the tier-2 entries (own) and trips (wave)
+            {
+                int trips = 0;
+                for (uint32_t m = bits; __any(m != 0); m &= m - 1) ++trips;
+                cnt += (trips << 12) + (__popc(bits) << 22);
+                bits = 0;
+            }
+#elif VO_SCORE_ABLATE == 1             // timing experiment only (wrong near the threshold)
+            bits = 0;
 #endif
-            cnt += c;
+            while (__any(bits != 0)) {
+                if (bits) {
+                    const int pos = 31 - __clz(bits);
+                    bits &= ~(1u << pos);
+                    const float4 v = spf[i0 + nb - 1 - pos];
+                    const int verdict = fund_filter(M, ff, v.x, v.y, v.z, v.w);
+                    int in = verdict > 0;
+                    if (verdict == 0) in = fund_err(M, v.x, v.y, v.z, v.w) <= a.thr2;
+                    cnt += in;
+                }
+            }
         }
-#pragma unroll 1
-        for (; i < np; ++i) cnt += exact(i);
     } else {
         auto one = [&](int i) {
             const double2 u = *(const double2*)(sp + 4 * i);
