@@ -191,6 +191,33 @@ int vo_match_compact(const int32_t* idx, const uint8_t* keep, int nq, int nt, in
 int vo_gen_subsets_device(const int32_t* n_dev, int N, int model_points, int H, const float* pts4,
                           int batch, int32_t* samples, int32_t* n_generated, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * The O(N) tail of the 2D-2D initialisation.
+ * ---------------------------------------------------------------------------------- */
+
+/* cv.triangulatePoints(projMatr1, projMatr2, projPoints1, projPoints2) -- reference
+ * src/utils/disambiguate_relative_pose.py:42, src/twoDtwoD.py:110, src/tracking.py:153.
+ * P1_host / P2_host: 3 x 4 row-major f64 on the host; x1, x2: N x 2 f64 pixel positions on the
+ * device (one row per point); X4: N x 4 homogeneous points, un-normalised (scale and sign as the
+ * SVD leaves them, like OpenCV). */
+int vo_triangulate(const double* P1_host, const double* P2_host, const double* x1, const double* x2,
+                   int N, double* X4, void* stream);
+
+/* For `batch` frame pairs straight from vo_ransac_batch(kind 0): E = K^T F K (reference
+ * src/utils/geometry.py:48-49), decomposeEssentialMatrix (src/utils/decompose_essential_matrix.py:4-37)
+ * and disambiguateRelativePose (src/utils/disambiguate_relative_pose.py:5-72) over the inliers in
+ * `mask`.  F batch x 9; result batch x 4 (pairs with result[4b] < 0 have no model and get the
+ * identity; NULL = all have one); mask batch x N; pts4 batch x N x 4 f32 (x_i y_i x_j y_j); n_dev
+ * per-pair counts or NULL; K_host 3 x 3 row-major (both cameras).  Outputs: cand batch x 4 x 12 the
+ * four [R|t] candidates in the reference's order (R0,+t R0,-t R1,+t R1,-t); score batch x 4 their
+ * cheirality scores; T batch x 16 = T_cami_camj of the first strict maximum; X batch x N x 4 the
+ * dehomogenised points in camera-i coordinates (zero rows where mask is 0); keep batch x N =
+ * mask & depth > min(0, T[2][2]) & |X| < max_depth.  The 3 x 3 SVD is a Jacobi SVD here and
+ * LAPACK in the reference: same candidate set, possibly in another order (see vo_pose.hip). */
+int vo_pose_tail_batch(const double* F, const int32_t* result, const uint8_t* mask, const float* pts4,
+                       const int32_t* n_dev, const double* K_host, int N, int batch, double max_depth,
+                       double* cand, int32_t* score, double* T, double* X, uint8_t* keep, void* stream);
+
 /* result (2 x int32): largest count and the lowest index holding it (pure argmax mode). */
 int vo_argmax_first(const int32_t* counts, int n, int32_t* result, void* stream);
 

@@ -82,3 +82,19 @@ def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs=None, rve
     ok, rv, tv, inl, _ = ransac.solve_pnp_ransac_p3p(objectPoints, imagePoints, cameraMatrix, iterationsCount,
                                                      reprojectionError, confidence)
     return ok, rv, tv, inl
+
+
+def triangulatePoints(projMatr1, projMatr2, projPoints1, projPoints2) -> np.ndarray:
+    """cv.triangulatePoints (reference src/utils/disambiguate_relative_pose.py:42, src/tracking.py:153):
+    (3,4) projection matrices, (2,N) points -> (4,N) homogeneous points, computed on the device."""
+    import torch
+    from . import ops
+    x1 = np.ascontiguousarray(np.asarray(projPoints1, dtype=np.float64).reshape(2, -1).T)
+    x2 = np.ascontiguousarray(np.asarray(projPoints2, dtype=np.float64).reshape(2, -1).T)
+    if x1.shape != x2.shape:
+        raise ValueError("triangulatePoints: point sets differ in length")
+    if x1.shape[0] == 0:
+        return np.zeros((4, 0))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    X = ops.triangulate(projMatr1, projMatr2, torch.from_numpy(x1).to(dev), torch.from_numpy(x2).to(dev))
+    return np.ascontiguousarray(X.cpu().numpy().T)

@@ -351,3 +351,49 @@ def gen_subsets(n_points: int, model_points: int, max_iters: int, pts4_host: Opt
     n = lib.vo_host_gen_subsets(int(n_points), int(model_points), int(max_iters), p, out.ctypes.data)
     _lib.check(n, "vo_host_gen_subsets")
     return out[:n]
+
+
+def _c12(P) -> "C.Array":
+    import ctypes as C
+    import numpy as np
+    a = np.ascontiguousarray(np.asarray(P, dtype=np.float64)).reshape(-1)
+    return (C.c_double * a.size)(*a.tolist())
+
+
+def triangulate(P1, P2, x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """cv.triangulatePoints on the device: P1, P2 (3,4) host; x1, x2 (N,2) f64 -> (N,4) f64 homogeneous."""
+    _lib.require_device()
+    x1 = _dev(x1, torch.float64, "x1").reshape(-1, 2)
+    x2 = _dev(x2, torch.float64, "x2").reshape(-1, 2)
+    if x1.shape != x2.shape:
+        raise _lib.VoError("triangulate: point sets differ in length")
+    X = torch.empty((x1.shape[0], 4), dtype=torch.float64, device=x1.device)
+    _lib.check(_lib.load().vo_triangulate(_c12(P1), _c12(P2), _ptr(x1), _ptr(x2), x1.shape[0], _ptr(X), _stream()),
+               "vo_triangulate")
+    return X
+
+
+def pose_tail_batch(F: torch.Tensor, mask: torch.Tensor, pts4: torch.Tensor, K, max_depth: float,
+                    result: Optional[torch.Tensor] = None, n_dev: Optional[torch.Tensor] = None):
+    """F (B,9) f64, mask (B,N) u8, pts4 (B,N,4) f32, K (3,3) host -> dict(cand (B,4,12), score (B,4) i32,
+    T (B,4,4), X (B,N,4), keep (B,N) u8); see vo_pose_tail_batch in include/vo_hip.h."""
+    _lib.require_device()
+    F = _dev(F, torch.float64, "F").reshape(-1, 9)
+    mask = _dev(mask, torch.uint8, "mask"); pts4 = _dev(pts4, torch.float32, "pts4")
+    B, N = mask.shape
+    if F.shape[0] != B or tuple(pts4.shape) != (B, N, 4):
+        raise _lib.VoError("pose_tail_batch: shape mismatch")
+    if result is not None:
+        result = _dev(result, torch.int32, "result")
+    if n_dev is not None:
+        n_dev = _dev(n_dev, torch.int32, "n_dev")
+    dev = F.device
+    cand = torch.empty((B, 4, 12), dtype=torch.float64, device=dev)
+    score = torch.empty((B, 4), dtype=torch.int32, device=dev)
+    T = torch.empty((B, 4, 4), dtype=torch.float64, device=dev)
+    X = torch.empty((B, N, 4), dtype=torch.float64, device=dev)
+    keep = torch.empty((B, N), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.load().vo_pose_tail_batch(_ptr(F), _ptr(result), _ptr(mask), _ptr(pts4), _ptr(n_dev), _c12(K), N, B,
+                                              float(max_depth), _ptr(cand), _ptr(score), _ptr(T), _ptr(X), _ptr(keep),
+                                              _stream()), "vo_pose_tail_batch")
+    return dict(cand=cand, score=score, T=T, X=X, keep=keep)

@@ -70,3 +70,14 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
         out.p_result, out.pose, out.rvec, out.p_mask = p_res, pose, rvec, p_mask
         out.p_samples, out.obj, out.img = p_samples, c["obj"], c["img"]
     return out
+
+
+def pose_tail(res: PairBatchResult, K, max_depth: Optional[float] = None):
+    """The 2D-2D pose tail of src/twoDtwoD.py:57-79 for every pair of `res`, on the device:
+    E = K^T F K -> decomposeEssentialMatrix -> disambiguateRelativePose over the F inliers.
+    -> dict(cand, score, T (B,4,4) = T_cami_camj, X (B,nq,4) points in camera-i coordinates, keep (B,nq) u8);
+    rows follow res.pts4 (matched correspondences, first n_match[b] used)."""
+    if max_depth is None:
+        from .params import get_params
+        max_depth = get_params().INIT_PARAMS.MAX_DEPTH_DISTANCE
+    return ops.pose_tail_batch(res.F, res.f_mask, res.pts4, K, max_depth, result=res.f_result, n_dev=res.n_match)

@@ -38,3 +38,18 @@ def calculate_relative_pose(points_i, points_j, K):
     T, _, _ = disambiguateRelativePose(R, u3, _homogeneous_inliers(points_i, mask_f),
                                        _homogeneous_inliers(points_j, mask_f), K, K)
     return T[:3, :3], T[:3, 3]
+
+
+def twoDtwoD_from_pipeline(res, tail, b: int, cam_to_world_i=None):
+    """The return tuple of src/twoDtwoD.py:57-79 for pair `b` of a device-resident batch
+    (``pipeline.match_and_ransac`` + ``pipeline.pose_tail``): only the small results are downloaded.
+    -> (M_camj_to_world (4,4), P_world (L,3), p_i (L,2), p_j (L,2))."""
+    n = int(res.n_match[b])
+    keep = tail["keep"][b, :n].cpu().numpy().astype(bool)
+    T = tail["T"][b].cpu().numpy()
+    P_cami = tail["X"][b, :n].cpu().numpy()[keep]
+    pts = res.pts4[b, :n].cpu().numpy().astype(np.float64)[keep]
+    M_cami_to_world = np.eye(4) if cam_to_world_i is None else np.asarray(cam_to_world_i)
+    M_camj_to_world = M_cami_to_world @ hom_inv(T)
+    P_world = M_cami_to_world @ P_cami.T
+    return M_camj_to_world, P_world[:3, :].T, pts[:, :2], pts[:, 2:]
