@@ -87,10 +87,12 @@ __host__ __device__ inline unsigned long long mulmod(unsigned long long x, unsig
     return r;
 }
 
+constexpr int kSubsetThreads = 256;   // speculative samples per round and problem (4 waves)
+
 struct SubsetArgs {
     const int32_t* n_dev; const float4* pts4; int32_t* samples; int32_t* n_generated;
     int N, model_points, H, check;
-    unsigned long long jump[65];      // a^(model_points * l) mod m, l = 0..64
+    unsigned long long jump[kSubsetThreads + 1];      // a^(model_points * l) mod m
 };
 
 // last point of the sample (near-)collinear with a pair of earlier ones, in image `off` (0 or 2)
@@ -115,15 +117,18 @@ __device__ inline bool collinear_last(const float4* pts, const int (&s)[COUNT], 
 }
 
 template <int M>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(kSubsetThreads)
 void gen_subsets_kernel(const SubsetArgs a)
 {
     constexpr int m = M;                                  // compile-time: the sample lives in registers
-    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ unsigned long long s_state[kSubsetThreads];
+    __shared__ unsigned long long s_odd[kSubsetThreads / 64], s_act[kSubsetThreads / 64];
+    __shared__ unsigned char s_fail[kSubsetThreads];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
     const int n = a.n_dev ? min(a.n_dev[b], a.N) : a.N;
     int32_t* out = a.samples + (size_t)b * a.H * m;
     const float4* pts = a.pts4 ? a.pts4 + (size_t)b * a.N : nullptr;
-    int done = 0;                                         // iterations generated so far (wave-uniform)
+    int done = 0;                                         // iterations generated so far (block-uniform)
     bool failed = n < m;
     // two plain steps bring the seed 0xFFFF...F into the canonical range [0, m) of the closed form;
     // they are real draws, so they are replayed below as the first two draws of iteration 0
@@ -132,12 +137,12 @@ void gen_subsets_kernel(const SubsetArgs a)
     while (!failed && done < a.H) {
         unsigned long long s;
         if (warm > 0) {
-            // the first chunk is one iteration wide: lane 0 walks the generator step by step
+            // the first chunk is one iteration wide: thread 0 walks the generator step by step
             s = base;
         } else {
-            s = mulmod(a.jump[lane], base);
+            s = mulmod(a.jump[tid], base);
         }
-        const bool active = warm > 0 ? lane == 0 : done + lane < a.H;
+        const bool active = warm > 0 ? tid == 0 : done + tid < a.H;
         int sub[M];
         int used = 0;
         bool ok = false;
@@ -160,27 +165,36 @@ void gen_subsets_kernel(const SubsetArgs a)
                 ok = !(a.check && pts) || (!collinear_last(pts, sub, 0) && !collinear_last(pts, sub, 2));
             }
         }
-        // lanes up to the first one that did not use exactly m draws started from the right state
+        // threads up to the first one that did not use exactly m draws started from the right state
         const unsigned long long odd = __ballot(active && (used != m || !ok));
         const unsigned long long act = __ballot(active);
-        const int nact = __popcll(act);
-        const int first_odd = odd ? __ffsll((long long)odd) - 1 : nact - 1;
-        const int accept = first_odd + 1;                 // lanes 0..first_odd are valid
-        const bool bad = __shfl((int)!ok, first_odd) != 0;    // that lane exhausted its 10000 attempts
-        const int nwrite = bad ? first_odd : accept;
-        if (active && lane < nwrite) {
+        if ((tid & 63) == 0) { s_odd[wave] = odd; s_act[wave] = act; }
+        s_state[tid] = s;
+        s_fail[tid] = !ok;
+        __syncthreads();
+        int nact = 0, first_odd = -1;
 #pragma unroll
-            for (int i = 0; i < m; ++i) out[(size_t)(done + lane) * m + i] = sub[i];
+        for (int w = 0; w < kSubsetThreads / 64; ++w) {
+            const unsigned long long o = s_odd[w];
+            if (first_odd < 0 && o) first_odd = 64 * w + __ffsll((long long)o) - 1;
+            nact += __popcll(s_act[w]);
+        }
+        if (first_odd < 0) first_odd = nact - 1;
+        const bool bad = s_fail[first_odd] != 0;          // that thread exhausted its 10000 attempts
+        const int nwrite = bad ? first_odd : first_odd + 1;
+        if (active && tid < nwrite) {
+#pragma unroll
+            for (int i = 0; i < m; ++i) out[(size_t)(done + tid) * m + i] = sub[i];
         }
         done += nwrite;
-        if (bad) { failed = true; break; }
-        const unsigned lo = __shfl((unsigned)s, first_odd), hi = __shfl((unsigned)(s >> 32), first_odd);
-        base = ((unsigned long long)hi << 32) | lo;       // generator state behind the last valid lane
+        base = s_state[first_odd];                        // generator state behind the last valid thread
         warm = 0;
+        __syncthreads();                                  // the shared arrays are rewritten next round
+        if (bad) failed = true;
     }
     // iterations that were never generated: mark "no sample" for the solvers
-    for (long i = (long)done * m + lane; i < (long)a.H * m; i += 64) out[i] = -1;
-    if (lane == 0 && a.n_generated) a.n_generated[b] = done;
+    for (long i = (long)done * m + tid; i < (long)a.H * m; i += kSubsetThreads) out[i] = -1;
+    if (tid == 0 && a.n_generated) a.n_generated[b] = done;
 }
 
 }  // namespace
@@ -217,11 +231,11 @@ extern "C" int vo_gen_subsets_device(const int32_t* n_dev, int N, int model_poin
     unsigned long long am = 1;
     for (int i = 0; i < model_points; ++i) am = mulmod(am, kA);
     a.jump[0] = 1;
-    for (int l = 1; l <= 64; ++l) a.jump[l] = mulmod(a.jump[l - 1], am);
+    for (int l = 1; l <= kSubsetThreads; ++l) a.jump[l] = mulmod(a.jump[l - 1], am);
     hipStream_t s = (hipStream_t)stream;
-    if (model_points == 4) hipLaunchKernelGGL(gen_subsets_kernel<4>, dim3(batch), dim3(64), 0, s, a);
-    else if (model_points == 5) hipLaunchKernelGGL(gen_subsets_kernel<5>, dim3(batch), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(gen_subsets_kernel<7>, dim3(batch), dim3(64), 0, s, a);
+    if (model_points == 4) hipLaunchKernelGGL(gen_subsets_kernel<4>, dim3(batch), dim3(kSubsetThreads), 0, s, a);
+    else if (model_points == 5) hipLaunchKernelGGL(gen_subsets_kernel<5>, dim3(batch), dim3(kSubsetThreads), 0, s, a);
+    else hipLaunchKernelGGL(gen_subsets_kernel<7>, dim3(batch), dim3(kSubsetThreads), 0, s, a);
     VO_LAUNCH_CHECK();
     return VO_OK;
 }
