@@ -126,7 +126,7 @@ __device__ __forceinline__ int fund_filter(const double* F, const FundFilter& f,
 // A model that is zero, NaN, Inf or scaled beyond 2^+-300 gets eta = Inf: every verdict is "cannot tell".
 struct FundFilter32 {
     float F[9];
-    float t, rel, eta2, c1, c2;
+    float tlo, thi, eta2, c;           // thr2 -+ 2^-17 thr2 (rounded outwards), 2 eta, constant term of m
 };
 
 __device__ __forceinline__ FundFilter32 fund_filter32_setup(const double* F, float thr2, double Q1, double Q2)
@@ -159,14 +159,19 @@ __device__ __forceinline__ FundFilter32 fund_filter32_setup(const double* F, flo
     const double al1 = 0x1p-21 * fmax((A[0] + A[3]) * Q2 + A[6], (A[1] + A[4]) * Q2 + A[7]);
     const double up = 1. + 0x1p-20;                              // constants are rounded to f32: round up
     const float inf = __builtin_huge_valf();
-    f.t = thr2;
-    f.rel = (float)(0x1p-17 * (double)thr2 * up);
+    const double al = fmax(al1, al2);
+    f.tlo = (float)((double)thr2 * (1. - 0x1p-17) * (1. - 0x1p-20));
+    f.thi = (float)((double)thr2 * (1. + 0x1p-17) * up);
     f.eta2 = usable ? (float)(2. * eta * up) : inf;
-    f.c1 = usable ? (float)(2. * (eta * eta + 0x1p22 * (double)thr2 * al1 * al1) * up) : inf;
-    f.c2 = usable ? (float)(2. * (eta * eta + 0x1p22 * (double)thr2 * al2 * al2) * up) : inf;
+    f.c = usable ? (float)(2. * (eta * eta + 0x1p22 * (double)thr2 * al * al) * up) : inf;
     return f;
 }
 
+// d1 and d2 of fund_err are two roundings of the same number x2^T F x1, and eta bounds the distance
+// of ANY evaluation of it from either, so one d serves both residuals; with c = max(c1, c2) the two
+// tests collapse onto the smaller denominator:
+//   sure inlier   <=>  d^2 + (eta2 |d| + c) < (thr2 - rel) min(den1, den2)
+//   sure outlier  <=>  d^2 - (eta2 |d| + c) > (thr2 + rel) min(den1, den2)
 __device__ __forceinline__ int fund_filter32(const FundFilter32& f, float x1, float y1, float x2, float y2)
 {
     const float* F = f.F;
@@ -174,17 +179,15 @@ __device__ __forceinline__ int fund_filter32(const FundFilter32& f, float x1, fl
     const float b1 = __builtin_fmaf(F[3], x1, __builtin_fmaf(F[4], y1, F[5]));
     const float c1 = __builtin_fmaf(F[6], x1, __builtin_fmaf(F[7], y1, F[8]));
     const float den2 = __builtin_fmaf(a1, a1, b1 * b1);
-    const float d2 = __builtin_fmaf(x2, a1, __builtin_fmaf(y2, b1, c1));
+    const float d = __builtin_fmaf(x2, a1, __builtin_fmaf(y2, b1, c1));
     const float a2 = __builtin_fmaf(F[0], x2, __builtin_fmaf(F[3], y2, F[6]));
     const float b2 = __builtin_fmaf(F[1], x2, __builtin_fmaf(F[4], y2, F[7]));
-    const float c2 = __builtin_fmaf(F[2], x2, __builtin_fmaf(F[5], y2, F[8]));
     const float den1 = __builtin_fmaf(a2, a2, b2 * b2);
-    const float d1 = __builtin_fmaf(x1, a2, __builtin_fmaf(y1, b2, c2));
-    const float z1 = __builtin_fmaf(-f.t, den1, d1 * d1), z2 = __builtin_fmaf(-f.t, den2, d2 * d2);
-    const float m1 = __builtin_fmaf(f.eta2, fabsf(d1), __builtin_fmaf(f.rel, den1, f.c1));
-    const float m2 = __builtin_fmaf(f.eta2, fabsf(d2), __builtin_fmaf(f.rel, den2, f.c2));
-    if ((z1 < -m1) & (z2 < -m2)) return 1;
-    if ((z1 > m1) | (z2 > m2)) return -1;
+    const float dmin = fminf(den1, den2);
+    const float mm = __builtin_fmaf(f.eta2, fabsf(d), f.c);
+    const float lo = __builtin_fmaf(d, d, mm), hi = __builtin_fmaf(d, d, -mm);
+    if (lo < f.tlo * dmin) return 1;
+    if (hi > f.thi * dmin) return -1;
     return 0;
 }
 
