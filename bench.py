@@ -41,7 +41,7 @@ H = 4096                      # RANSAC iterations (sample sets) per problem
 RATIO = 0.8                   # reference src/params.py:10
 F_THR, F_CONF = 0.1, 0.9999   # reference src/params.py:24-27
 P_THR, P_CONF = 1.0, 0.9999   # reference src/params.py:72-75
-FIRST_BLOCK = 256             # PnP iterations evaluated before the first early-termination check
+FIRST_BLOCK = 64              # PnP iterations evaluated before the first early-termination check (then x5 per block)
 K = synth.K_MALAGA
 SIZE = synth.IMAGE_SIZE["malaga"]
 
@@ -61,9 +61,7 @@ class PairSet:
         self.pairs = pairs
         self.q, self.t = up("q"), up("t")                       # (B, N, 128) f32
         self.kp_q, self.kp_t, self.xyz_q = up("kp_q"), up("kp_t"), up("xyz_q")
-        lib = _lib.load()
-        nbytes = max(16, lib.vo_knn2_workspace_bytes(NQ, NT, pairs), lib.vo_ransac_workspace_bytes(0, H, pairs),
-                     lib.vo_ransac_workspace_bytes(2, H, pairs))
+        nbytes = pipeline.workspace_bytes(NQ, NT, pairs, H, H)
         self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
 
 
@@ -229,11 +227,16 @@ def main():
                        "traffic_note": tnote,
                        "note": "effective streaming bytes (16 B per model x correspondence); the tiled kernel "
                                "re-uses points from LDS so physical HBM traffic is far lower and the real limiter "
-                               "is the f64 VALU",
-                       "f64_tflops": evals_f * 49 / avg["score_fund"] / 1e12, "f64_peak_tflops": FP64_PEAK_TFLOPS,
+                               "is VALU issue: ~25 f32 ops per evaluation in the filter tier, the f64 filter / exact "
+                               "f64 evaluation only within rounding distance of the threshold (DESIGN.md 7)",
+                       "f64_tflops_equivalent": evals_f * 49 / avg["score_fund"] / 1e12,
+                       "f64_equivalent_note": "49 f64 flops per evaluation of the scalar definition whose verdicts the kernel "
+                                              "reproduces bit for bit; not executed as such (f64 vector peak is 78.6 TFLOP/s)",
                        "units_per_launch": f"{evals_f} evaluations = {n_models_f} models x the pair's correspondences ({B} frame pairs)"},
         "score_pnp": {"kernel": "score_kernel<PnP>", "bound": "hbm", "achieved": sp_gbs, "peak": HBM_PEAK_GBS,
-                      "unit": "GB/s", "frac": sp_gbs / HBM_PEAK_GBS, "traffic": traffic.get("score_pnp_kernel"),
+                      "unit": "GB/s", "frac": sp_gbs / HBM_PEAK_GBS, "traffic": None,
+                      "note": "the PnP chain runs on a side stream underneath the F chain's getSubset/solver kernels, "
+                              "so these launches share the GPU and their durations are upper bounds",
                       "units_per_launch": f"{evals_p} evaluations = {n_models_p} models x the pair's correspondences "
                                           f"({B} frame pairs, {len(iteration_blocks(FIRST_BLOCK))} iteration-block launches summed)"},
         "knn2": {"kernel": "knn2_partial_kernel", "bound": "mfma", "achieved": knn_tops, "peak": i8_peak_tops,

@@ -345,22 +345,31 @@ void desc_f32_to_i8_kernel(const float* __restrict__ desc, int n, int8_t* __rest
     if (bad) atomicOr(flags, bad);
 }
 
+// grid-stride, one atomic per workgroup: a counter bumped once per wave serialises the whole launch
+// on one L2 channel (~10 ns per atomic)
 __global__ __launch_bounds__(256)
 void ratio_test_kernel(const int32_t* __restrict__ d2, int n, double ratio,
                        uint8_t* __restrict__ keep, int32_t* __restrict__ count)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int k = 0;
-    if (i < n) {
+    __shared__ int s_cnt[4];
+    int mine = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int2 d = *(const int2*)(d2 + 2 * (size_t)i);
+        int k = 0;
         if (d.x != INT_MAX && d.y != INT_MAX) {
             const float m = __fsqrt_rn((float)d.x), s = __fsqrt_rn((float)d.y);
             k = (double)m < ratio * (double)s;
         }
         keep[i] = (uint8_t)k;
+        mine += k;
     }
-    const unsigned long long bal = __ballot(k);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(count, __popcll(bal));
+    for (int o = 32; o; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (t) atomicAdd(count, t);
+    }
 }
 
 struct KnnPlan { int nsplit, rows_per_split, nqb; };
@@ -464,7 +473,8 @@ extern "C" int vo_ratio_test(const int32_t* d2, int n, double ratio, uint8_t* ke
     VO_CHECK_ARG(n >= 0, VO_EINVAL, "vo_ratio_test: negative size");
     if (n == 0) return VO_OK;
     VO_CHECK_ARG(d2 && keep && count, VO_EINVAL, "vo_ratio_test: null pointer");
-    hipLaunchKernelGGL(ratio_test_kernel, dim3(vo_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+    const int blocks = vo_ceil_div(n, 256) < 1024 ? vo_ceil_div(n, 256) : 1024;
+    hipLaunchKernelGGL(ratio_test_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        d2, n, ratio, keep, count);
     VO_LAUNCH_CHECK();
     return VO_OK;

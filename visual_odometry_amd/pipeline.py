@@ -36,6 +36,44 @@ class PairBatchResult:
     img: Optional[torch.Tensor] = None
 
 
+_side = {}
+
+
+def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=dev)
+    return _side[key]
+
+
+def workspace_bytes(nq: int, nt: int, batch: int, f_iters: int, p_iters: int = 0) -> int:
+    """Bytes of scratch `match_and_ransac` wants in one buffer: the kNN pass and the two RANSAC runs
+    (which may overlap in time, so they get disjoint parts)."""
+    lib = ops._lib.load()
+    r = _ws_align(lib.vo_ransac_workspace_bytes(ops.KIND_FUND, f_iters, batch))
+    if p_iters > 0:
+        r += _ws_align(lib.vo_ransac_workspace_bytes(ops.KIND_PNP, p_iters, batch))
+    return max(16, lib.vo_knn2_workspace_bytes(nq, nt, batch), r)
+
+
+def _ws_align(nbytes: int) -> int:
+    return (nbytes + 255) // 256 * 256
+
+
+def _split_workspace(workspace, f_iters, p_iters, batch):
+    """Disjoint parts of the caller's buffer for the F and the PnP run, or (None, None) when it is
+    absent or too small (each run then allocates its own)."""
+    if workspace is None:
+        return None, None
+    lib = ops._lib.load()
+    nf = _ws_align(lib.vo_ransac_workspace_bytes(ops.KIND_FUND, f_iters, batch))
+    np_ = _ws_align(lib.vo_ransac_workspace_bytes(ops.KIND_PNP, p_iters, batch)) if p_iters > 0 else 0
+    flat = workspace.reshape(-1).view(torch.uint8)
+    if flat.numel() < nf + np_:
+        return None, None
+    return flat[:nf], (flat[nf:nf + np_] if np_ else None)
+
+
 def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Tensor, kp_t: torch.Tensor, ratio: float,
                      f_threshold: float, f_confidence: float, f_iters: int,
                      xyz_q: Optional[torch.Tensor] = None, K=None, p_threshold: float = 1.0, p_confidence: float = 0.9999,
@@ -56,19 +94,33 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
     keep, _ = ops.ratio_test(d2.reshape(B * nq, 2), ratio)
     c = ops.match_compact(idx, keep.reshape(B, nq), kp_q, kp_t, xyz_q if p_iters > 0 else None)
     n = c["n"]
+    # The PnP chain needs nothing from the F chain, and the F chain starts with the latency-bound
+    # getSubset kernel (a few workgroups per pair): run PnP on a side stream underneath it.
+    main = torch.cuda.current_stream()
+    do_pnp = p_iters > 0 and xyz_q is not None
+    ws_f, ws_p = _split_workspace(workspace, f_iters, p_iters if do_pnp else 0, B)
+    pnp_out = None
+    if do_pnp:
+        side = _side_stream(desc_q.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            n_p = torch.where(n >= 5, n, torch.zeros_like(n))
+            p_samples, _ = ops.gen_subsets_device(n_p, nq, 4, p_iters, None)
+            p_res, pose, rvec, p_mask = ops.ransac_batch(ops.KIND_PNP, p_samples, c["obj"], p_threshold, p_confidence, p_iters,
+                                                         img=c["img"], K=K, n_dev=n_p, workspace=ws_p, first_block=first_block_pnp)
+            pnp_out = (p_res, pose, rvec, p_mask, p_samples)
+            for t in pnp_out + (n_p,):
+                t.record_stream(main)              # allocated on the side stream, consumed on the caller's
     # fewer than 15 matches: OpenCV would not run 7-point RANSAC; feed an empty problem instead
     n_f = torch.where(n >= 15, n, torch.zeros_like(n))
     f_samples, _ = ops.gen_subsets_device(n_f, nq, 7, f_iters, c["pts4"])
     f_res, F, _, f_mask = ops.ransac_batch(ops.KIND_FUND, f_samples, c["pts4"], f_threshold, f_confidence, f_iters,
-                                           n_dev=n_f, workspace=workspace, first_block=first_block_f)
+                                           n_dev=n_f, workspace=ws_f, first_block=first_block_f)
     out = PairBatchResult(idx, d2, c["match_q"], c["match_t"], n, c["pts4"], f_res, F, f_mask, f_samples=f_samples)
-    if p_iters > 0 and xyz_q is not None:
-        n_p = torch.where(n >= 5, n, torch.zeros_like(n))
-        p_samples, _ = ops.gen_subsets_device(n_p, nq, 4, p_iters, None)
-        p_res, pose, rvec, p_mask = ops.ransac_batch(ops.KIND_PNP, p_samples, c["obj"], p_threshold, p_confidence, p_iters,
-                                                     img=c["img"], K=K, n_dev=n_p, workspace=workspace, first_block=first_block_pnp)
-        out.p_result, out.pose, out.rvec, out.p_mask = p_res, pose, rvec, p_mask
-        out.p_samples, out.obj, out.img = p_samples, c["obj"], c["img"]
+    if do_pnp:
+        main.wait_stream(side)
+        out.p_result, out.pose, out.rvec, out.p_mask, out.p_samples = pnp_out
+        out.obj, out.img = c["obj"], c["img"]
     return out
 
 
