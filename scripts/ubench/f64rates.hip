@@ -11,6 +11,7 @@ __global__ __launch_bounds__(256) void k(double* out, int iters, double seed)
 #pragma unroll
     for (int i = 0; i < 8; ++i) a[i] = seed + threadIdx.x * 1e-3 + i;
     const double m = 1.0000001, c = 1e-9;
+    const int seed_i = (int)seed;
     int cnt = 0;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -26,6 +27,13 @@ __global__ __launch_bounds__(256) void k(double* out, int iters, double seed)
                 if (OP == 6) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
                 if (OP == 7) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(*(float*)&a[i]), "v"((float)m) : "vcc");
                 if (OP == 8) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(*(float*)&a[i]) : "v"((float)m));
+                if (OP == 9) asm volatile("v_med3_i32 %0, %0, %1, %2" : "+v"(*(int*)&a[i]) : "v"(it), "v"(seed_i));
+                if (OP == 10) asm volatile("v_max_i32 %0, %0, %1" : "+v"(*(int*)&a[i]) : "v"(it));
+                if (OP == 11) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(*(float*)&a[i]) : "v"((float)m), "v"((float)c));
+                if (OP == 12) asm volatile("v_max_f32 %0, %0, %1" : "+v"(*(float*)&a[i]) : "v"((float)m));
+                if (OP == 13) asm volatile("v_lshl_add_u32 %0, %0, 9, %1" : "+v"(*(int*)&a[i]) : "v"(it));
+                if (OP == 14) asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(*(int*)&a[i]));
+                if (OP == 15) asm volatile("v_add_u32 %0, %0, %1" : "+v"(*(int*)&a[i]) : "v"(it));
             }
         }
     }
@@ -58,8 +66,9 @@ void run(const char* name, int wg_per_cu)
 
 int main()
 {
-    for (int w : {2, 8}) {
+    for (int w : {2, 4}) {
         run<0>("v_fma_f64", w); run<1>("v_mul_f64", w); run<2>("v_add_f64", w); run<3>("v_cmp_lt_f64", w); run<4>("v_fma_f32", w); run<5>("v_pk_fma_f32", w); run<6>("v_pk_mul_f32", w); run<7>("v_cmp_lt_f32", w); run<8>("v_mul_f32", w);
+        run<9>("v_med3_i32", w); run<10>("v_max_i32", w); run<11>("v_med3_f32", w); run<12>("v_max_f32", w); run<13>("v_lshl_add_u32", w); run<14>("v_cvt_f32_i32", w); run<15>("v_add_u32", w);
     }
     return 0;
 }

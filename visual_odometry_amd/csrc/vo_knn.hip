@@ -98,6 +98,12 @@ __device__ __forceinline__ int med3i(int a, int b, int c)
     return r;
 }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+__device__ __forceinline__ int max3i_op(int a, int b, int c)
+{
+    int r;
+    asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -200,18 +206,21 @@ void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict_
         }
     };
 
-    // top-2 update of one 32x32 tile of dot products: 3 VALU ops per element
+    // top-2 update of one 32x32 tile of dot products, two keys at a time: with m1 >= m2 the two largest
+    // of {m1, m2, p0, p1} are max3(m1, p0, p1) and max(m2, med3(m1, p0, p1)): 2.5 VALU ops per element
+    // (key build included)
     auto epilogue = [&](const v16i& acc, const v4i* cv, int set) {
 #if VO_ABLATE == 1          /* experiment: no top-2 epilogue */
         asm volatile("" :: "v"(acc));
         m1[set][0] = max(m1[set][0], cv[0][0] + cv[1][1] + cv[2][2] + cv[3][3]);
 #else
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int p = (acc[r] << 9) + cv[r >> 2][r & 3];
-            const int c = r & 1;
-            m2[set][c] = med3i(m1[set][c], m2[set][c], p);
-            m1[set][c] = max(m1[set][c], p);
+        for (int r = 0; r < 16; r += 2) {
+            const int p0 = (acc[r] << 9) + cv[r >> 2][r & 3];
+            const int p1 = (acc[r + 1] << 9) + cv[r >> 2][(r & 3) + 1];
+            const int c = (r >> 1) & 1;
+            m2[set][c] = max(m2[set][c], med3i(m1[set][c], p0, p1));
+            m1[set][c] = max3i_op(m1[set][c], p0, p1);
         }
 #endif
     };
