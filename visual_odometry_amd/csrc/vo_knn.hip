@@ -31,6 +31,12 @@
 #ifndef VO_KNN_TILES
 #define VO_KNN_TILES 4       /* 32-row train tiles per LDS stage */
 #endif
+#ifndef VO_KNN_PIPE
+#define VO_KNN_PIPE 0        /* 1: MFMAs of the next tile issued ahead of the current tile's epilogue (measured: no gain) */
+#endif
+#ifndef VO_KNN_CHAINS
+#define VO_KNN_CHAINS 2      /* independent top-2 lists per query set in the epilogue (1, 2 or 4) */
+#endif
 #ifndef VO_KNN_MINW
 #define VO_KNN_MINW 2        /* waves per SIMD the register allocation must allow */
 #endif
@@ -49,6 +55,7 @@ constexpr int kChunkTiles = VO_KNN_TILES;
 constexpr int kChunkRows = kTileRows * kChunkTiles;          // 128 train rows per LDS stage
 constexpr int kSegTiles = 16;                                 // tile index bits in the key
 constexpr int kSets = VO_KNN_SETS;                                      // 32-query sets per wave
+constexpr int kChains = VO_KNN_CHAINS;
 constexpr int kWaveQ = 32 * kSets;                            // query rows per wave
 constexpr int kWgWaves = VO_KNN_WAVES;
 constexpr int kWgQ = kWaveQ * kWgWaves;                       // 256 query rows per workgroup
@@ -181,18 +188,22 @@ void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict_
     Top2 run[kSets];
 #pragma unroll
     for (int set = 0; set < kSets; ++set) { run[set].k1 = run[set].k2 = INT_MIN; run[set].j1 = run[set].j2 = -1; }
-    int m1[kSets][2], m2[kSets][2];  // [set][chain] packed running top-2 of the current segment
+    int m1[kSets][kChains], m2[kSets][kChains];  // [set][chain] packed running top-2 of the current segment
 #pragma unroll
     for (int set = 0; set < kSets; ++set)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) m1[set][c] = m2[set][c] = INT_MIN;
+        for (int c = 0; c < kChains; ++c) m1[set][c] = m2[set][c] = INT_MIN;
 
     auto fold = [&](int seg_row_base) {
 #pragma unroll
         for (int set = 0; set < kSets; ++set) {
-            const int a1 = m1[set][0], a2 = m2[set][0], b1 = m1[set][1], b2 = m2[set][1];
-            const int n1 = max(a1, b1);
-            const int n2 = max3i(min(a1, b1), a2, b2);
+            int n1 = m1[set][0], n2 = m2[set][0];
+#pragma unroll
+            for (int c = 1; c < kChains; ++c) {
+                const int b1 = m1[set][c], b2 = m2[set][c];
+                n2 = max3i(min(n1, b1), n2, b2);
+                n1 = max(n1, b1);
+            }
             const int pv[2] = {n1, n2};
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -202,7 +213,8 @@ void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict_
                 const int j = p == INT_MIN ? -1 : seg_row_base + tile16 * kTileRows + i;
                 insert_later(run[set], p >> 8, j);
             }
-            m1[set][0] = m2[set][0] = m1[set][1] = m2[set][1] = INT_MIN;
+#pragma unroll
+            for (int c = 0; c < kChains; ++c) m1[set][c] = m2[set][c] = INT_MIN;
         }
     };
 
@@ -218,7 +230,7 @@ void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict_
         for (int r = 0; r < 16; r += 2) {
             const int p0 = (acc[r] << 9) + cv[r >> 2][r & 3];
             const int p1 = (acc[r + 1] << 9) + cv[r >> 2][(r & 3) + 1];
-            const int c = (r >> 1) & 1;
+            const int c = (r >> 1) & (kChains - 1);
             m2[set][c] = max(m2[set][c], med3i(m1[set][c], p0, p1));
             m1[set][c] = max3i_op(m1[set][c], p0, p1);
         }
@@ -243,6 +255,44 @@ void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict_
 #pragma unroll
         for (int s = 0; s < 4; ++s) foff[s] = ((2 * s + h) ^ ((qrow >> 1) & 7)) << 4;
 
+#if VO_KNN_PIPE
+        // Software pipeline inside the wave: the four MFMAs of unit u+1 (a 32x32 tile of one query set)
+        // are issued BEFORE the top-2 epilogue of unit u, whose VALU work then runs while the matrix
+        // pipe is busy.  The register allocation leaves two waves per SIMD, both of this workgroup and
+        // nearly in phase, so overlap across waves alone does not happen.
+        {
+            constexpr int kUnits = kChunkTiles * kSets;
+            v4i va[4], cvb[2][4];
+            v16i accb[2];
+            auto load_tile = [&](int tile, int slot) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) va[s] = *(const v4i*)(fbase + tile * kTileRows * kDim + foff[s]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) cvb[slot][g] = *(const v4i*)(cbase + tile * kTileRows + 8 * g + 4 * h);
+            };
+            auto issue = [&](int set, int slot) {
+                v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(va[s], qb[set][s], acc, 0, 0, 0);
+                accb[slot] = acc;
+            };
+            load_tile(0, 0);
+            issue(0, 0);
+#pragma unroll
+            for (int u = 0; u < kUnits; ++u) {
+                const int tile = u / kSets, set = u % kSets;
+                if (u + 1 < kUnits) {
+                    const int ntile = (u + 1) / kSets, nset = (u + 1) % kSets;
+                    if (nset == 0) load_tile(ntile, ntile & 1);
+                    issue(nset, (u + 1) & 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                epilogue(accb[u & 1], cvb[tile & 1], set);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#else
         // no software pipelining: 4 waves per SIMD (two 8-wave workgroups per CU) cover the MFMA
         // chain latency and the LDS reads of one wave with the top-2 VALU work of the others
 #pragma unroll
@@ -267,6 +317,7 @@ void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict_
             }
         }
 
+#endif
         if (VO_ABLATE != 4 && VO_ABLATE != 5 && chunk + 1 < nchunks) stage_c(chunk + 1, buf ^ 1);
         if (((chunk + 1) & (kSegTiles / kChunkTiles - 1)) == 0 || chunk + 1 == nchunks)
             fold(row0 + (chunk / (kSegTiles / kChunkTiles)) * (kSegTiles * kTileRows));
