@@ -8,21 +8,17 @@ for tag, cn in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
     for r in csv.DictReader(open(f"gpurun_out/pmc_{tag}/pmc_counter_collection.csv")):
         k = r["Kernel_Name"]
         short = ("knn2_partial_kernel" if "knn2_partial" in k else "score_fund_kernel" if "score_kernel<0>" in k
-                 else "score_pnp_kernel" if "score_kernel<2>" in k else None)
+                 else None)
         if short and r["Counter_Name"] == cn:
             acc[short].append(float(r["Counter_Value"]))
     for k, v in acc.items():
-        if k == "score_pnp_kernel":           # three iteration-block launches per step: report their sum per step
-            per = sum(v) / (len(v) / 3.0)
-        else:
-            per = sum(v) / len(v)
+        per = sum(v) / len(v)
         out.setdefault(k, {})[cn + "_KB_per_launch"] = per
 for k, d in out.items():
     d["hbm_bytes_per_launch"] = int(2 * d["FETCH_SIZE_KB_per_launch"] * 1024 + d["WRITE_SIZE_KB_per_launch"] * 1024)
 out["_pairs"] = pairs
 out["_how"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of `python3 bench.py --steps 2 --warmup 1 "
-               f"--no-cpu` ({pairs} frame pairs per launch), averaged over launches (PnP scoring: sum of its three "
-               "iteration-block launches); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at "
+               f"--no-cpu` ({pairs} frame pairs per launch), averaged over launches; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at "
                "64 B); KB as reported by rocprofv3")
 json.dump(out, open("profiles/r1_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
