@@ -102,6 +102,25 @@ def test_score_fund_filter_degenerate_and_scaled(oracle_mod, dev, fund_models):
             assert np.array_equal(cnt, ref), (scale, poison, thr, np.nonzero(cnt != ref)[0][:10])
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_score_fund_fuzz(oracle_mod, dev, seed):
+    """random scenes, image scales, model scalings and thresholds (from 0.01 px to 30 px): counts equal
+    the scalar definition whatever tier of the filter decides."""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(33, 2500))
+    sc = synth.two_view_scene(n, seed=200 + seed, outlier_frac=float(rng.uniform(0, 0.6)), noise_px=float(rng.uniform(0, 2)))
+    scale = float(10 ** rng.uniform(-2, 2))
+    p1 = (sc["p1"] * scale).astype(np.float32); p2 = (sc["p2"] * scale).astype(np.float32)
+    subs = oracle_mod.gen_subsets(n, 7, 150, p1, p2)
+    models = np.array([F.reshape(9) for s_ in subs for F in oracle_mod.run7point(p1[s_], p2[s_])])
+    models = models * (10 ** rng.uniform(-30, 30, (len(models), 1)))          # F is defined up to scale
+    pts4 = np.concatenate([p1, p2], 1).astype(np.float32)
+    for thr in 10 ** rng.uniform(-2, 1.5, 4) * scale:
+        cnt = ops.score_fund(_d(models, dev), _d(pts4, dev), float(thr)).cpu().numpy()
+        ref = np.array([oracle_mod.find_inliers(oracle_mod.fund_error(m, p1, p2), float(thr))[0] for m in models])
+        assert np.array_equal(cnt, ref), (seed, thr, np.nonzero(cnt != ref)[0][:5])
+
+
 def test_score_valid_flags_and_empty(dev, fund_models):
     sc, p1, p2, models = fund_models
     pts4 = np.concatenate([p1, p2], 1).astype(np.float32)
