@@ -47,6 +47,22 @@ def _w_gather(rank, world):
     return bool(torch.equal(got, full))
 
 
+def _w_sweep_tables(rank, world):
+    """the sweep's pair dealing and table gather (the per-pair device work is replaced by a formula)."""
+    from visual_odometry_amd import parallel as par, sweep
+    ids = list(range(5, 42, 3))
+    mine = par.round_robin(ids, rank, world)
+    tab = np.zeros(len(mine), dtype=sweep.TABLE_DTYPE)
+    tab["pair"] = mine
+    tab["n_match"] = [7 * i + 1 for i in mine]
+    tab["rot_err_deg"] = [0.5 * i for i in mine]
+    got = sweep.gather_tables(tab, par.WORLD)
+    if rank != 0:
+        return got is None
+    return bool(list(got["pair"]) == ids and list(got["n_match"]) == [7 * i + 1 for i in ids]
+                and np.allclose(got["rot_err_deg"], [0.5 * i for i in ids]))
+
+
 def _w_best(rank, world):
     from visual_odometry_amd import parallel as par
     rng = np.random.default_rng(0)                       # same vector on every rank
@@ -119,3 +135,8 @@ def test_sharded_ransac_equals_unsharded(oracle_mod, world):
     for r in res:
         assert r[:4] == tuple(int(v) for v in info)
         assert np.array_equal(np.array(r[4]).reshape(3, 3), F)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sweep_tables_gather(world):
+    assert all(_run("_w_sweep_tables", world))

@@ -105,3 +105,27 @@ def test_pair_pipeline_matches_oracle_chain(det_math, dev):
         assert tuple(r.p_result[b].cpu().numpy()) == tuple(int(v) for v in pinfo)
         pm = r.p_mask[b].cpu().numpy()
         assert np.array_equal(np.nonzero(pm[:n[b]])[0], inl.ravel()) and not pm[n[b]:].any()
+
+
+def test_sweep_device_generated_pairs_vs_oracle(det_math, dev):
+    """sweep.run_sweep: pairs generated on the device, table rows checked against the oracle chain on
+    the same (downloaded) data; the recovered pose is the scene's."""
+    from visual_odometry_amd import sweep
+    o = det_math
+    K, size = synth.K_MALAGA, synth.IMAGE_SIZE["malaga"]
+    ids = [3, 11, 12, 40, 41]
+    tab = sweep.run_sweep(ids, 1200, 1300, 2, dev, K=K, size=size, f_threshold=1.0, f_confidence=0.999, f_iters=300,
+                          p_threshold=2.0, p_confidence=0.999, p_iters=300)
+    assert list(tab["pair"]) == sorted(ids)
+    for row in tab:
+        p = sweep.frame_pair_device(int(row["pair"]), 1200, 1300, K, size, dev)      # same seed -> same pair
+        q, t = p["q"].cpu().numpy(), p["t"].cpu().numpy()
+        assert q.min() >= 0 and q.max() <= 255 and np.array_equal(q, np.rint(q)) and 400 < np.linalg.norm(q, axis=1).mean() < 600
+        oq, ot, _, _ = o.match_features_indices(q, t, 0.8)
+        assert row["n_match"] == len(oq) > 300
+        p1, p2 = p["kp_q"].cpu().numpy()[oq], p["kp_t"].cpu().numpy()[ot]
+        F, mask, info = o.find_fundamental_mat(p1, p2, 1.0, 0.999, 300)
+        assert (row["f_iter"], row["f_model"], row["f_inliers"], row["f_niters"]) == tuple(int(v) for v in info)
+        ok, rvec, tvec, inl, pinfo = o.solve_pnp_ransac(p["xyz_q"].cpu().numpy()[oq], p2, K, 300, 2.0, 0.999)
+        assert (row["p_iter"], row["p_model"], row["p_inliers"], row["p_niters"]) == tuple(int(v) for v in pinfo)
+        assert row["tail_kept"] > 0.5 * row["f_inliers"] and row["rot_err_deg"] < 1.0 and row["t_dir_err_deg"] < 15.0
