@@ -298,26 +298,3 @@ def test_pose_tail_against_reference_helpers(oracle_mod):
             assert np.allclose(r, R, atol=1e-12) and np.allclose(u, u3, atol=1e-12)
         assert np.allclose(hom_inv(T), Tinv, atol=1e-15) and np.allclose(oracle_mod.hom_inv(T), Tinv, atol=1e-15)
         assert np.allclose(hom_inv(T) @ T, np.eye(4), atol=1e-12)
-
-
-def test_triangulation_and_disambiguation(oracle_mod, capsys):
-    from visual_odometry_amd.utils.decompose_essential_matrix import decomposeEssentialMatrix
-    from visual_odometry_amd.utils.disambiguate_relative_pose import disambiguateRelativePose
-    from visual_odometry_amd.utils.triangulate import triangulatePoints
-    for seed in range(4):
-        sc = synth.two_view_scene(400, seed=50 + seed, noise_px=0.2, outlier_frac=0.1)
-        K, R, t = sc["K"], sc["R"], sc["t"]
-        P1, P2 = K @ np.eye(3, 4), K @ np.c_[R, t]
-        a = triangulatePoints(P1, P2, sc["p1"].T, sc["p2"].T)
-        b = oracle_mod.triangulate_points(P1, P2, sc["p1"].T.astype(np.float64), sc["p2"].T.astype(np.float64))
-        assert np.allclose(a / a[3], b / b[3], rtol=1e-7, atol=1e-7)
-        good = sc["inlier"]
-        assert np.abs((a / a[3])[:3, good].T - sc["X"][good]).max() < 0.2 * 40
-        E = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
-        Rs, u3 = decomposeEssentialMatrix(E)
-        p1h = np.c_[sc["p1"].astype(np.float64), np.ones(400)].T; p2h = np.c_[sc["p2"].astype(np.float64), np.ones(400)].T
-        T, P, mask = disambiguateRelativePose(Rs, u3, p1h, p2h, K, K)
-        oT, oP, omask = oracle_mod.disambiguate_relative_pose(Rs, u3, p1h, p2h, K, K)
-        assert "rejected points during 3D reconstruction" in capsys.readouterr().out
-        assert np.array_equal(T, oT) and np.array_equal(mask, omask) and np.allclose(P, oP, rtol=1e-6, atol=1e-6)
-        assert np.allclose(T[:3, :3], R, atol=1e-9) and np.allclose(T[:3, 3], t, atol=1e-9)
