@@ -66,10 +66,12 @@ class PairSet:
 
 
 def step(ps: PairSet):
-    """One pass over all pairs; everything is enqueued on the current stream, nothing is read back."""
+    """One pass over all pairs; everything is enqueued (main stream + the pipeline's PnP side stream),
+    nothing is read back.  The PnP tail of one step may still be running when the next step starts; the
+    timed region ends with a device-wide synchronize."""
     return pipeline.match_and_ransac(ps.q, ps.t, ps.kp_q, ps.kp_t, RATIO, F_THR, F_CONF, H, xyz_q=ps.xyz_q, K=K,
                                      p_threshold=P_THR, p_confidence=P_CONF, p_iters=H, first_block_pnp=FIRST_BLOCK,
-                                     workspace=ps.ws)
+                                     workspace=ps.ws, wait_pnp=False)
 
 
 def cpu_baseline(max_seconds: float = 25.0):

@@ -218,6 +218,18 @@ int vo_pose_tail_batch(const double* F, const int32_t* result, const uint8_t* ma
                        const int32_t* n_dev, const double* K_host, int N, int batch, double max_depth,
                        double* cand, int32_t* score, double* T, double* X, uint8_t* keep, void* stream);
 
+/* The EPnP refit cv.solvePnPRansac runs on the inliers of the winning P3P model (reference
+ * src/pnp.py:16-26: the pose `pnp` returns), for `batch` pairs straight from vo_ransac_batch(kind 2):
+ * obj batch x N x 3 f32, img batch x N x 2 f32, mask batch x N (the PnP inlier masks), n_dev per-pair
+ * counts or NULL, result batch x 4 or NULL (pairs with result[4b] < 0 have no model), K4_host =
+ * fx fy cx cy.  Outputs: Rt batch x 12 f64 (R row-major, then t; world -> camera as OpenCV returns
+ * it), ok batch (1 = pose, 0 = no model / fewer than 4 inliers / degenerate geometry, Rt zeroed).
+ * Device counterpart of vo_host_epnp; agrees with it to rounding (block reductions instead of
+ * sequential sums). */
+int vo_epnp_batch(const float* obj, const float* img, const uint8_t* mask, const int32_t* n_dev,
+                  const int32_t* result, const double* K4_host, int N, int batch, double* Rt, int32_t* ok,
+                  void* stream);
+
 /* result (2 x int32): largest count and the lowest index holding it (pure argmax mode). */
 int vo_argmax_first(const int32_t* counts, int n, int32_t* result, void* stream);
 

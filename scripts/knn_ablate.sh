@@ -8,7 +8,7 @@ if [ "$1" = build ]; then
   mkdir -p ablate
   for v in 1 2 4 5; do
     d=ablate/obj$v; mkdir -p $d
-    for f in vo_runtime vo_knn vo_score vo_ransac vo_solvers vo_epnp vo_pipeline vo_pose; do
+    for f in vo_runtime vo_knn vo_score vo_ransac vo_solvers vo_epnp vo_epnp_dev vo_pipeline vo_pose; do
       if [ $f = vo_knn ] || [ ! -f $d/$f.o ]; then
         /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DVO_ABLATE=$v -c visual_odometry_amd/csrc/$f.hip -o $d/$f.o
       fi

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 VARIANTS="2:8:4:2:2 2:8:4:2:4 2:8:4:2:1 2:8:4:3:2 1:8:4:4:4 2:4:4:2:4 2:8:8:2:4 4:4:4:1:2"
 if [ "$1" = build ]; then
   mkdir -p ablate/objv
-  for f in vo_runtime vo_score vo_ransac vo_solvers vo_epnp vo_pipeline vo_pose; do
+  for f in vo_runtime vo_score vo_ransac vo_solvers vo_epnp vo_epnp_dev vo_pipeline vo_pose; do
     [ -f ablate/objv/$f.o ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -w -c visual_odometry_amd/csrc/$f.hip -o ablate/objv/$f.o
   done
   for v in $VARIANTS; do

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 VARS="1_1 2_1 4_1 8_1 4_2 8_2"
 if [ "$1" = build ]; then
   mkdir -p ablate/vobj
-  for f in vo_runtime vo_knn vo_ransac vo_solvers vo_epnp vo_pipeline vo_pose; do
+  for f in vo_runtime vo_knn vo_ransac vo_solvers vo_epnp vo_epnp_dev vo_pipeline vo_pose; do
     [ -f ablate/vobj/$f.o ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -w -Iinclude -c visual_odometry_amd/csrc/$f.hip -o ablate/vobj/$f.o
   done
   for v in $VARS; do

@@ -129,3 +129,28 @@ def test_sweep_device_generated_pairs_vs_oracle(det_math, dev):
         ok, rvec, tvec, inl, pinfo = o.solve_pnp_ransac(p["xyz_q"].cpu().numpy()[oq], p2, K, 300, 2.0, 0.999)
         assert (row["p_iter"], row["p_model"], row["p_inliers"], row["p_niters"]) == tuple(int(v) for v in pinfo)
         assert row["tail_kept"] > 0.5 * row["f_inliers"] and row["rot_err_deg"] < 1.0 and row["t_dir_err_deg"] < 15.0
+
+
+def test_deferred_pnp_wait_gives_the_same_results(dev):
+    """wait_pnp=False: back-to-back calls sharing one workspace (the PnP tail of a call overlaps the next
+    call's matching) must give what the synchronous calls give."""
+    B, nq, nt = 3, 1500, 1700
+    K = synth.K_MALAGA
+    sets = [[_pair(700 + 10 * s + b, nq, nt) for b in range(B)] for s in range(3)]
+    ws = torch.empty((pipeline.workspace_bytes(nq, nt, B, 300, 400),), dtype=torch.uint8, device=dev)
+    def run(pairs, wait):
+        st = lambda k: _d(np.stack([p[k] for p in pairs]), dev)
+        return pipeline.match_and_ransac(st(0), st(1), st(2), st(3), 0.8, 1.0, 0.999, 300, xyz_q=st(4), K=K, p_threshold=2.0,
+                                         p_confidence=0.999, p_iters=400, first_block_pnp=64, workspace=ws, wait_pnp=wait)
+    ref = []
+    for pairs in sets:
+        r = run(pairs, True)
+        torch.cuda.synchronize()
+        ref.append({k: getattr(r, k).cpu().numpy() for k in ("n_match", "f_result", "F", "p_result", "pose", "p_mask", "pose_refined", "p_ok")})
+    outs = [run(pairs, False) for pairs in sets]            # nothing waits in between
+    for r in outs:
+        r.wait_pnp()
+    torch.cuda.synchronize()
+    for r, want in zip(outs, ref):
+        for k, v in want.items():
+            assert np.array_equal(getattr(r, k).cpu().numpy(), v), k

@@ -171,3 +171,55 @@ def test_triangulation_and_disambiguation_drop_ins(det_math, dev, capsys):
         assert np.array_equal(T, oT) and np.array_equal(mask, omask) and np.array_equal(P, oP)
         assert np.allclose(T[:3, :3], R, atol=1e-9) and np.allclose(T[:3, 3], t, atol=1e-9)
 
+
+
+def test_epnp_batch_vs_host_and_oracle(oracle_mod, dev):
+    """device EPnP over masked correspondences of a ragged batch vs the host refit and the oracle."""
+    from visual_odometry_amd.epnp import epnp_pose
+    sizes = [3000, 500, 40, 8, 6, 5, 3, 700]
+    N = max(sizes)
+    K = synth.K_MALAGA
+    rng = np.random.default_rng(3)
+    obj = np.zeros((len(sizes), N, 3), np.float32); img = np.zeros((len(sizes), N, 2), np.float32)
+    mask = np.zeros((len(sizes), N), np.uint8); result = np.zeros((len(sizes), 4), np.int32)
+    for b, n in enumerate(sizes):
+        ps = synth.pnp_scene(max(n, 8), K=K, seed=70 + b, outlier_frac=0.3 if n > 50 else 0.0, noise_px=0.4)
+        obj[b, :n], img[b, :n] = ps["obj"][:n], ps["img"][:n]
+        mask[b, :n] = ps["inlier"][:n] & (rng.uniform(size=n) < 0.9 if n > 50 else True)
+    result[7, 0] = -1                                      # "no model" pair
+    Rt, ok = ops.epnp_batch(_d(obj, dev), _d(img, dev), _d(mask, dev), K, n_dev=_d(np.array(sizes, np.int32), dev),
+                            result=_d(result, dev))
+    Rt, ok = Rt.cpu().numpy(), ok.cpu().numpy()
+    for b, n in enumerate(sizes):
+        sel = mask[b, :n].astype(bool)
+        if b == 7 or sel.sum() < 4:
+            assert ok[b] == 0 and not Rt[b].any()
+            continue
+        o64, i64 = obj[b, :n][sel].astype(np.float64), img[b, :n][sel].astype(np.float64)
+        hok, hR, ht = epnp_pose(o64, i64, K)
+        ook, oR, ot = oracle_mod.epnp(o64, i64, K)
+        assert ok[b] == 1 and hok and ook
+        R, t = Rt[b, :9].reshape(3, 3), Rt[b, 9:]
+        assert np.allclose(R, hR, rtol=1e-6, atol=1e-8) and np.allclose(t, ht.ravel(), rtol=1e-6, atol=1e-8), b
+        assert np.allclose(R, oR, rtol=1e-6, atol=1e-8) and np.allclose(t, ot.ravel(), rtol=1e-6, atol=1e-8), b
+        assert abs(np.linalg.det(R) - 1) < 1e-9
+
+
+def test_pipeline_refined_pose_equals_pnp_drop_in(det_math, dev):
+    """pipeline.match_and_ransac's pose_refined = what cv.solvePnPRansac (oracle) returns for the pair."""
+    from test_pipeline_gpu import _pair
+    from visual_odometry_amd.rodrigues import rodrigues_vector_to_matrix
+    o = det_math
+    B, nq, nt = 2, 1500, 1700
+    pairs = [_pair(500 + b, nq, nt) for b in range(B)]
+    st = lambda k: _d(np.stack([p[k] for p in pairs]), dev)
+    K = synth.K_MALAGA
+    r = pipeline.match_and_ransac(st(0), st(1), st(2), st(3), 0.8, 1.0, 0.999, 200, xyz_q=st(4), K=K, p_threshold=2.0,
+                                  p_confidence=0.999, p_iters=300, first_block_pnp=64)
+    Rt, okd = r.pose_refined.cpu().numpy(), r.p_ok.cpu().numpy()
+    for b, (q, t, kq, kt, xyz) in enumerate(pairs):
+        oq, ot, _, _ = o.match_features_indices(q, t, 0.8)
+        ok, rvec, tvec, inl, _ = o.solve_pnp_ransac(xyz[oq], kt[ot], K, 300, 2.0, 0.999)
+        assert ok and okd[b] == 1
+        assert np.allclose(Rt[b, :9].reshape(3, 3), rodrigues_vector_to_matrix(rvec.ravel()), rtol=1e-6, atol=1e-8)
+        assert np.allclose(Rt[b, 9:], tvec.ravel(), rtol=1e-6, atol=1e-8)

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "vo_gen_subsets_device": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "vo_triangulate": (_i, [C.POINTER(_d), C.POINTER(_d), _vp, _vp, _i, _vp, _vp]),
     "vo_pose_tail_batch": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_d), _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vo_epnp_batch": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_d), _i, _i, _vp, _vp, _vp]),
     "vo_ransac_workspace_bytes": (_sz, [_i, _i, _i]),
     "vo_ransac_batch": (_i, [_i, _vp, _i, _vp, _vp, C.POINTER(_d), _i, _vp, _i, _f, _d, _i, _i, _vp, _vp, _vp, _vp,
                              _vp, _sz, _vp]),

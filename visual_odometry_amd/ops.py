@@ -397,3 +397,23 @@ def pose_tail_batch(F: torch.Tensor, mask: torch.Tensor, pts4: torch.Tensor, K, 
                                               float(max_depth), _ptr(cand), _ptr(score), _ptr(T), _ptr(X), _ptr(keep),
                                               _stream()), "vo_pose_tail_batch")
     return dict(cand=cand, score=score, T=T, X=X, keep=keep)
+
+
+def epnp_batch(obj: torch.Tensor, img: torch.Tensor, mask: torch.Tensor, K, n_dev: Optional[torch.Tensor] = None,
+               result: Optional[torch.Tensor] = None):
+    """EPnP over the masked correspondences of every pair: obj (B,N,3) f32, img (B,N,2) f32, mask (B,N) u8
+    -> Rt (B,12) f64 [R row-major | t], ok (B,) i32."""
+    _lib.require_device()
+    obj = _dev(obj, torch.float32, "obj"); img = _dev(img, torch.float32, "img"); mask = _dev(mask, torch.uint8, "mask")
+    B, N = mask.shape
+    if tuple(obj.shape) != (B, N, 3) or tuple(img.shape) != (B, N, 2):
+        raise _lib.VoError("epnp_batch: shape mismatch")
+    if n_dev is not None:
+        n_dev = _dev(n_dev, torch.int32, "n_dev")
+    if result is not None:
+        result = _dev(result, torch.int32, "result")
+    Rt = torch.empty((B, 12), dtype=torch.float64, device=mask.device)
+    ok = torch.empty((B,), dtype=torch.int32, device=mask.device)
+    _lib.check(_lib.load().vo_epnp_batch(_ptr(obj), _ptr(img), _ptr(mask), _ptr(n_dev), _ptr(result), _K4(K), N, B,
+                                         _ptr(Rt), _ptr(ok), _stream()), "vo_epnp_batch")
+    return Rt, ok

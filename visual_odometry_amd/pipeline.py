@@ -30,6 +30,14 @@ class PairBatchResult:
     pose: Optional[torch.Tensor] = None          # (B,12) f64 [R|t] of the best P3P model (before the EPnP refit)
     rvec: Optional[torch.Tensor] = None          # (B,3) f64
     p_mask: Optional[torch.Tensor] = None        # (B,nq) u8
+    pose_refined: Optional[torch.Tensor] = None  # (B,12) f64 [R|t] of the EPnP refit over the PnP inliers: what cv.solvePnPRansac returns
+    p_ok: Optional[torch.Tensor] = None          # (B,) i32 1 where pose_refined holds a pose
+    pnp_done: Optional["torch.cuda.Event"] = None  # recorded behind the PnP chain (see wait_pnp)
+
+    def wait_pnp(self) -> None:
+        """Make the current stream wait for the PnP results (only needed after wait_pnp=False)."""
+        if self.pnp_done is not None:
+            torch.cuda.current_stream().wait_event(self.pnp_done)
     f_samples: Optional[torch.Tensor] = None     # (B,f_iters,7) i32 the sample streams used
     p_samples: Optional[torch.Tensor] = None
     obj: Optional[torch.Tensor] = None           # (B,nq,3) f32 / (B,nq,2) f32: the PnP correspondences
@@ -42,46 +50,53 @@ _side = {}
 def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
     if key not in _side:
-        _side[key] = torch.cuda.Stream(device=dev)
+        # high priority: the chain's kernels are small and would otherwise starve behind the F scoring
+        # launch that fills the GPU from the main stream
+        _side[key] = torch.cuda.Stream(device=dev, priority=-1)
     return _side[key]
 
 
 def workspace_bytes(nq: int, nt: int, batch: int, f_iters: int, p_iters: int = 0) -> int:
-    """Bytes of scratch `match_and_ransac` wants in one buffer: the kNN pass and the two RANSAC runs
-    (which may overlap in time, so they get disjoint parts)."""
+    """Bytes of scratch `match_and_ransac` wants in one buffer: the kNN pass and the two RANSAC runs, which
+    may all overlap in time (PnP of one call with the kNN of the next when wait_pnp=False), so they get
+    disjoint parts."""
     lib = ops._lib.load()
     r = _ws_align(lib.vo_ransac_workspace_bytes(ops.KIND_FUND, f_iters, batch))
     if p_iters > 0:
         r += _ws_align(lib.vo_ransac_workspace_bytes(ops.KIND_PNP, p_iters, batch))
-    return max(16, lib.vo_knn2_workspace_bytes(nq, nt, batch), r)
+    return _ws_align(max(16, lib.vo_knn2_workspace_bytes(nq, nt, batch))) + r
 
 
 def _ws_align(nbytes: int) -> int:
     return (nbytes + 255) // 256 * 256
 
 
-def _split_workspace(workspace, f_iters, p_iters, batch):
-    """Disjoint parts of the caller's buffer for the F and the PnP run, or (None, None) when it is
-    absent or too small (each run then allocates its own)."""
+def _split_workspace(workspace, nq, nt, f_iters, p_iters, batch):
+    """Disjoint parts of the caller's buffer for the kNN pass, the F and the PnP run, or Nones when it is
+    absent or too small (each stage then allocates its own)."""
     if workspace is None:
-        return None, None
+        return None, None, None
     lib = ops._lib.load()
     nf = _ws_align(lib.vo_ransac_workspace_bytes(ops.KIND_FUND, f_iters, batch))
     np_ = _ws_align(lib.vo_ransac_workspace_bytes(ops.KIND_PNP, p_iters, batch)) if p_iters > 0 else 0
+    nk = _ws_align(max(16, lib.vo_knn2_workspace_bytes(nq, nt, batch)))
     flat = workspace.reshape(-1).view(torch.uint8)
-    if flat.numel() < nf + np_:
-        return None, None
-    return flat[:nf], (flat[nf:nf + np_] if np_ else None)
+    if flat.numel() < nk + nf + np_:
+        return None, None, None
+    return flat[:nk], flat[nk:nk + nf], (flat[nk + nf:nk + nf + np_] if np_ else None)
 
 
 def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Tensor, kp_t: torch.Tensor, ratio: float,
                      f_threshold: float, f_confidence: float, f_iters: int,
                      xyz_q: Optional[torch.Tensor] = None, K=None, p_threshold: float = 1.0, p_confidence: float = 0.9999,
                      p_iters: int = 0, first_block_f: int = 0, first_block_pnp: int = 0,
-                     workspace: Optional[torch.Tensor] = None) -> PairBatchResult:
+                     workspace: Optional[torch.Tensor] = None, wait_pnp: bool = True) -> PairBatchResult:
     """desc_* (B,n,128) f32 integer-valued, kp_* (B,n,2) f32, xyz_q (B,nq,3) f32 landmarks of the query
     keypoints (enables the PnP run when p_iters > 0).  first_block_*: see ops.ransac_batch (0 = evaluate all
-    iterations at once).  Everything is enqueued on the current stream.
+    iterations at once).  Everything is enqueued on the current stream, except the PnP chain (P3P RANSAC +
+    EPnP refit), which runs on a high-priority side stream; with wait_pnp=True (default) the current
+    stream waits for it before returning, with wait_pnp=False the caller does (`result.wait_pnp()`), which
+    lets the small, latency-bound PnP kernels of one batch fill the gaps of the next batch's big ones.
 
     Per pair the RANSAC runs see exactly the correspondences, in the order, that the reference's
     gathers would hand to cv2 -- so results equal the single-pair entry points'.  Pairs with fewer
@@ -90,25 +105,28 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
     B, nq, nt = desc_q.shape[0], desc_q.shape[1], desc_t.shape[1]
     qi8, qn, _ = ops.desc_to_i8(desc_q.reshape(B * nq, 128))
     ti8, tn, _ = ops.desc_to_i8(desc_t.reshape(B * nt, 128))
-    idx, d2 = ops.knn2(qi8.reshape(B, nq, 128), qn.reshape(B, nq), ti8.reshape(B, nt, 128), tn.reshape(B, nt), workspace)
+    do_pnp = p_iters > 0 and xyz_q is not None
+    ws_k, ws_f, ws_p = _split_workspace(workspace, nq, nt, f_iters, p_iters if do_pnp else 0, B)
+    idx, d2 = ops.knn2(qi8.reshape(B, nq, 128), qn.reshape(B, nq), ti8.reshape(B, nt, 128), tn.reshape(B, nt), ws_k)
     keep, _ = ops.ratio_test(d2.reshape(B * nq, 2), ratio)
     c = ops.match_compact(idx, keep.reshape(B, nq), kp_q, kp_t, xyz_q if p_iters > 0 else None)
     n = c["n"]
     # The PnP chain needs nothing from the F chain, and the F chain starts with the latency-bound
     # getSubset kernel (a few workgroups per pair): run PnP on a side stream underneath it.
     main = torch.cuda.current_stream()
-    do_pnp = p_iters > 0 and xyz_q is not None
-    ws_f, ws_p = _split_workspace(workspace, f_iters, p_iters if do_pnp else 0, B)
     pnp_out = None
     if do_pnp:
         side = _side_stream(desc_q.device)
         side.wait_stream(main)
+        for t in (c["obj"], c["img"], n):
+            t.record_stream(side)                  # allocated on the caller's stream, read on the side stream
         with torch.cuda.stream(side):
             n_p = torch.where(n >= 5, n, torch.zeros_like(n))
             p_samples, _ = ops.gen_subsets_device(n_p, nq, 4, p_iters, None)
             p_res, pose, rvec, p_mask = ops.ransac_batch(ops.KIND_PNP, p_samples, c["obj"], p_threshold, p_confidence, p_iters,
                                                          img=c["img"], K=K, n_dev=n_p, workspace=ws_p, first_block=first_block_pnp)
-            pnp_out = (p_res, pose, rvec, p_mask, p_samples)
+            refined, p_ok = ops.epnp_batch(c["obj"], c["img"], p_mask, K, n_dev=n_p, result=p_res)
+            pnp_out = (p_res, pose, rvec, p_mask, p_samples, refined, p_ok)
             for t in pnp_out + (n_p,):
                 t.record_stream(main)              # allocated on the side stream, consumed on the caller's
     # fewer than 15 matches: OpenCV would not run 7-point RANSAC; feed an empty problem instead
@@ -118,8 +136,10 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
                                            n_dev=n_f, workspace=ws_f, first_block=first_block_f)
     out = PairBatchResult(idx, d2, c["match_q"], c["match_t"], n, c["pts4"], f_res, F, f_mask, f_samples=f_samples)
     if do_pnp:
-        main.wait_stream(side)
-        out.p_result, out.pose, out.rvec, out.p_mask, out.p_samples = pnp_out
+        out.pnp_done = side.record_event()
+        if wait_pnp:
+            main.wait_event(out.pnp_done)
+        out.p_result, out.pose, out.rvec, out.p_mask, out.p_samples, out.pose_refined, out.p_ok = pnp_out
         out.obj, out.img = c["obj"], c["img"]
     return out
 
