@@ -252,10 +252,10 @@ def main():
     line = {
         "metric": "matched frame-pairs/sec", "value": pairs_total / dt, "unit": "frame-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8 (matching) / f64 (RANSAC)",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8 (matching) / f64 (RANSAC; F scoring filtered in f32, verdicts identical)",
         "data": "synthetic",
         "config": {"workload": "cfg4: 8192x8192x128 SIFT match + ratio test -> matched correspondences (on device) -> "
-                               "4096-iteration 7-point F-RANSAC and 4096-iteration P3P PnP-RANSAC over them, per frame pair",
+                               "4096-iteration 7-point F-RANSAC and 4096-iteration P3P PnP-RANSAC (+ EPnP refit of its inliers) over them, per frame pair",
                    "pairs_per_gpu_per_step": B, "parallelism": f"pairs sharded over {world} GPU(s), no collective"},
         "ransac_scoring": {"metric": "RANSAC hypotheses x points scored/sec",
                            "value": evals_f / avg["score_fund"],
