@@ -244,7 +244,7 @@ def main():
         "knn2": {"kernel": "knn2_partial_kernel", "bound": "mfma", "achieved": knn_tops, "peak": i8_peak_tops,
                  "unit": "TOP/s", "frac": knn_tops / i8_peak_tops, "traffic": traffic.get("knn2_partial_kernel"),
                  "note": f"int8 dense peak = {cus} CU x {I8_OPS_PER_CLK_CU} ops/clk x {clock_ghz} GHz; the sweep is bound by "
-                         "VALU issue (3 integer ops per distance for the exact top-2), see DESIGN.md",
+                         "VALU issue (2.5 integer ops per distance for the exact top-2), see DESIGN.md",
                  "units_per_launch": f"{B} frame pairs of {NQ} x {NT} descriptors"},
     }
     dominant = max(tot, key=tot.get)

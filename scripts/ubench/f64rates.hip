@@ -34,6 +34,16 @@ __global__ __launch_bounds__(256) void k(double* out, int iters, double seed)
                 if (OP == 13) asm volatile("v_lshl_add_u32 %0, %0, 9, %1" : "+v"(*(int*)&a[i]) : "v"(it));
                 if (OP == 14) asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(*(int*)&a[i]));
                 if (OP == 15) asm volatile("v_add_u32 %0, %0, %1" : "+v"(*(int*)&a[i]) : "v"(it));
+                if (OP == 16) asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(*(int*)&a[i]) : "v"(it), "v"(seed_i));
+                if (OP == 17) asm volatile("v_lshlrev_b32 %0, 9, %0" : "+v"(*(int*)&a[i]));
+                if (OP == 18) asm volatile("v_or_b32 %0, %0, %1" : "+v"(*(int*)&a[i]) : "v"(it));
+                if (OP == 19) asm volatile("v_max_u32 %0, %0, %1" : "+v"(*(int*)&a[i]) : "v"(it));
+                if (OP == 20) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(*(int*)&a[i]) : "v"(it), "v"(seed_i));
+                if (OP == 21) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(*(int*)&a[i]) : "v"(it), "v"(seed_i));
+                if (OP == 22) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(*(int*)&a[i]) : "v"(it));
+                if (OP == 23) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(*(int*)&a[i]) : "v"(it));
+                if (OP == 24) asm volatile("v_max_f32 %0, %0, %1" : "+v"(*(float*)&a[i]) : "v"((float)m));
+                if (OP == 25) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(*(int*)&a[i]) : "v"(it));
             }
         }
     }
@@ -66,9 +76,11 @@ void run(const char* name, int wg_per_cu)
 
 int main()
 {
-    for (int w : {2, 4}) {
+    for (int w : {4}) {
         run<0>("v_fma_f64", w); run<1>("v_mul_f64", w); run<2>("v_add_f64", w); run<3>("v_cmp_lt_f64", w); run<4>("v_fma_f32", w); run<5>("v_pk_fma_f32", w); run<6>("v_pk_mul_f32", w); run<7>("v_cmp_lt_f32", w); run<8>("v_mul_f32", w);
         run<9>("v_med3_i32", w); run<10>("v_max_i32", w); run<11>("v_med3_f32", w); run<12>("v_max_f32", w); run<13>("v_lshl_add_u32", w); run<14>("v_cvt_f32_i32", w); run<15>("v_add_u32", w);
+        run<16>("v_mad_i32_i24", w); run<17>("v_lshlrev_b32", w); run<18>("v_or_b32", w); run<19>("v_max_u32", w); run<20>("v_max3_i32", w);
+        run<21>("v_add3_u32", w); run<22>("v_sub_u32", w); run<23>("v_cndmask_b32", w); run<25>("v_pk_max_i16", w);
     }
     return 0;
 }
