@@ -34,14 +34,17 @@ __host__ __device__ inline int update_num_iters(double p, double ep, int model_p
 // modelPoints-1): exactly the entries the sequential loop would accept, as long as the loop is still
 // running.  Records of a step are found with a wave prefix-max + ballot and handed, in order, to
 // thread 0, which applies RANSACUpdateNumIters and stops the scan where OpenCV's loop would have.
-constexpr int kReplayThreads = 1024;
-
+// Two workgroup sizes: 1024 threads for long tables (fewest barrier rounds), 256 for short ones -- a
+// 1024-thread workgroup cannot get a CU while another stream's big launch keeps refilling every slot
+// with its own small workgroups, a 256-thread one can (the PnP chain runs beside the F scoring launch).
+template <int kReplayThreads>
 __global__ __launch_bounds__(kReplayThreads)
 void ransac_replay_kernel(const int32_t* __restrict__ counts, const int32_t* __restrict__ nmodels,
                           int n_iters, int max_models, int n_points, const int32_t* __restrict__ n_dev,
                           int model_points, double confidence, int max_iters, int32_t* __restrict__ result)
 {
-    __shared__ int s_wmax[16], s_wcnt[16];
+    constexpr int kReplayWaves = kReplayThreads / 64;
+    __shared__ int s_wmax[kReplayWaves], s_wcnt[kReplayWaves];
     __shared__ int2 s_rec[kReplayThreads];
     __shared__ int s_niters, s_good, s_best_iter, s_best_k, s_stop;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
@@ -80,7 +83,7 @@ void ransac_replay_kernel(const int32_t* __restrict__ counts, const int32_t* __r
         __syncthreads();
         int before = carry, all = carry;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
+        for (int w = 0; w < kReplayWaves; ++w) {
             const int m = s_wmax[w];
             if (w < wave) before = before > m ? before : m;
             all = all > m ? all : m;
@@ -92,7 +95,7 @@ void ransac_replay_kernel(const int32_t* __restrict__ counts, const int32_t* __r
         __syncthreads();
         int off = __popcll(bal & ((1ull << lane) - 1)), total = 0;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
+        for (int w = 0; w < kReplayWaves; ++w) {
             const int c = s_wcnt[w];
             if (w < wave) off += c;
             total += c;
@@ -184,8 +187,12 @@ int vo_launch_replay(const int32_t* counts, const int32_t* nmodels, int n_iters,
                      int32_t* result, hipStream_t s)
 {
     if (batch == 0) return VO_OK;
-    hipLaunchKernelGGL(ransac_replay_kernel, dim3(batch), dim3(kReplayThreads), 0, s, counts, nmodels, n_iters,
-                       max_models, n_points, n_dev, model_points, confidence, max_iters, result);
+    if ((long)n_iters * max_models > 4096)
+        hipLaunchKernelGGL(ransac_replay_kernel<1024>, dim3(batch), dim3(1024), 0, s, counts, nmodels, n_iters,
+                           max_models, n_points, n_dev, model_points, confidence, max_iters, result);
+    else
+        hipLaunchKernelGGL(ransac_replay_kernel<256>, dim3(batch), dim3(256), 0, s, counts, nmodels, n_iters,
+                           max_models, n_points, n_dev, model_points, confidence, max_iters, result);
     VO_LAUNCH_CHECK();
     return VO_OK;
 }
