@@ -230,6 +230,14 @@ int vo_epnp_batch(const float* obj, const float* img, const uint8_t* mask, const
                   const int32_t* result, const double* K4_host, int N, int batch, double* Rt, int32_t* ok,
                   void* stream);
 
+/* The ranking step of OpenCV's LMedS registrator, which cv2.findFundamentalMat(..., cv2.RANSAC, ...)
+ * silently uses for 8..14 points (reference src/utils/geometry.py:39 with few matches):
+ * medians[h] = the f32 error of rank N/2 of model h over the N correspondences (errors ordered as
+ * their int reinterpretation, as std::nth_element over errf.ptr<int>() does); +Inf where valid[h]
+ * is 0.  models H x 9, pts N x 4 f32 (x1 y1 x2 y2), N <= 64. */
+int vo_lmeds_median_fund(const double* models, const uint8_t* valid, int H, const float* pts, int N,
+                         float* medians, void* stream);
+
 /* result (2 x int32): largest count and the lowest index holding it (pure argmax mode). */
 int vo_argmax_first(const int32_t* counts, int n, int32_t* result, void* stream);
 

@@ -55,6 +55,9 @@ def _sig(lib):
     lib.vo_or_find_fundamental_ransac.argtypes = [_c_f32p, _c_f32p, C.c_int, C.c_double, C.c_double,
                                                   C.c_int, C.c_int, _c_f64p, _c_u8p, _c_i32p]
     lib.vo_or_find_fundamental_ransac.restype = C.c_int
+    lib.vo_or_find_fundamental_lmeds.argtypes = [_c_f32p, _c_f32p, C.c_int, C.c_double, C.c_int, C.c_int,
+                                                 _c_f64p, _c_u8p, _c_i32p]
+    lib.vo_or_find_fundamental_lmeds.restype = C.c_int
     lib.vo_or_sampson_error.argtypes = [_c_f64p, _c_f64p, _c_f64p, C.c_int, _c_f32p]
     lib.vo_or_run5point.argtypes = [_c_f64p, _c_f64p, _c_f64p]
     lib.vo_or_run5point.restype = C.c_int
@@ -198,7 +201,10 @@ def find_fundamental_mat(points1, points2, thr, conf, max_iters, hartley: bool =
     F = np.zeros(9, dtype=np.float64)
     mask = np.zeros(n, dtype=np.uint8)
     info = np.zeros(4, dtype=np.int32)
-    ok = lib().vo_or_find_fundamental_ransac(m1, m2, n, thr, conf, max_iters, int(hartley), F, mask, info)
+    if 8 <= n <= 14:                  # OpenCV 4.6.0 switches to LMedS below 15 points (A.3)
+        ok = lib().vo_or_find_fundamental_lmeds(m1, m2, n, conf, max_iters, int(hartley), F, mask, info)
+    else:
+        ok = lib().vo_or_find_fundamental_ransac(m1, m2, n, thr, conf, max_iters, int(hartley), F, mask, info)
     return (F.reshape(3, 3) if ok else None), mask.reshape(-1, 1), info
 
 

@@ -182,3 +182,68 @@ done:
     free(err); free(cur); free(subsets);
     return result;
 }
+
+
+/* findFundamentalMat with 8..14 points: OpenCV 4.6.0 takes the LMedS registrator even when the
+ * caller asked for RANSAC (createLMeDSPointSetRegistrator in ptsetreg.cpp, restated
+ * from its published behaviour -- OpenCV absent => parity unpinned): the iteration count is fixed up
+ * front from an assumed outlier ratio of 0.45 (at least 3), every model's errors are ranked as the
+ * int reinterpretation of the f32 values and the element at rank count/2 is its median, the first
+ * strictly smallest median wins, inliers are the points within sigma = 2.5 * 1.4826 *
+ * (1 + 5/(count - 7)) * sqrt(median) (at least 0.001).  info: best iteration, best model, inlier
+ * count, iterations run.  Returns 1 when the inlier count reaches 7. */
+static int cmp_i32(const void* a, const void* b)
+{
+    int32_t x = *(const int32_t*)a, y = *(const int32_t*)b;
+    return x < y ? -1 : x > y;
+}
+
+int vo_or_find_fundamental_lmeds(const float* m1, const float* m2, int n, double conf, int max_iters,
+                                 int hartley, double* F9, uint8_t* mask, int32_t* info)
+{
+    const int mp = 7;
+    info[0] = info[1] = -1; info[2] = 0; info[3] = 0;
+    if (n <= mp) return 0;
+    if (conf < DBL_EPSILON || conf > 1 - DBL_EPSILON) conf = 0.99;
+    int niters = vo_or_update_num_iters(conf, 0.45, mp, max_iters);
+    if (niters < 3) niters = 3;
+    info[3] = niters;
+    float* err = (float*)malloc(sizeof(float) * n);
+    int32_t* key = (int32_t*)malloc(sizeof(int32_t) * n);
+    int32_t* subsets = (int32_t*)malloc(sizeof(int32_t) * mp * (size_t)niters);
+    int n_gen = vo_or_gen_subsets(n, mp, niters, 1, m1, m2, subsets);
+    double min_median = DBL_MAX;
+    int result = 0;
+    for (int iter = 0; iter < niters && iter < n_gen; ++iter) {
+        float s1[14], s2[14];
+        double F27[27];
+        for (int i = 0; i < mp; ++i) {
+            int v = subsets[iter * mp + i];
+            s1[2 * i] = m1[2 * v]; s1[2 * i + 1] = m1[2 * v + 1];
+            s2[2 * i] = m2[2 * v]; s2[2 * i + 1] = m2[2 * v + 1];
+        }
+        int nm = vo_or_run7point(s1, s2, F27, hartley);
+        for (int k = 0; k < nm; ++k) {
+            vo_or_fund_error(F27 + 9 * k, m1, m2, n, err);
+            memcpy(key, err, sizeof(float) * n);
+            qsort(key, n, sizeof(int32_t), cmp_i32);
+            float mf;
+            memcpy(&mf, key + n / 2, sizeof(float));
+            double median = mf;
+            if (median < min_median) {
+                min_median = median;
+                memcpy(F9, F27 + 9 * k, 9 * sizeof(double));
+                info[0] = iter; info[1] = k;
+            }
+        }
+    }
+    if (min_median < DBL_MAX) {
+        double sigma = 2.5 * 1.4826 * (1 + 5. / (n - mp)) * sqrt(min_median);
+        if (sigma < 0.001) sigma = 0.001;
+        vo_or_fund_error(F9, m1, m2, n, err);
+        info[2] = vo_or_find_inliers(err, n, sigma, mask);
+        result = info[2] >= mp;
+    }
+    free(err); free(key); free(subsets);
+    return result;
+}

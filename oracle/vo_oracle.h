@@ -69,6 +69,9 @@ int  vo_or_run7point(const float* ms1, const float* ms2, double* F27, int hartle
 int  vo_or_find_fundamental_ransac(const float* m1, const float* m2, int n, double thr,
                                    double conf, int max_iters, int hartley,
                                    double* F9, uint8_t* mask, int32_t* info);
+/* the LMedS registrator OpenCV 4.6.0 uses for 8..14 points (A.3) */
+int  vo_or_find_fundamental_lmeds(const float* m1, const float* m2, int n, double conf, int max_iters,
+                                  int hartley, double* F9, uint8_t* mask, int32_t* info);
 
 /* ---- A.4 essential matrix ------------------------------------------------------- */
 void vo_or_sampson_error(const double* E, const double* x1, const double* x2, int n, float* err);

@@ -242,13 +242,57 @@ def test_find_fundamental_end_to_end(det_math, dev, n, thr, conf, iters, seed):
         assert np.array_equal(F, oF)
 
 
+@pytest.mark.parametrize("n", [8, 9, 11, 14])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_find_fundamental_lmeds_8_to_14_points(det_math, dev, n, seed):
+    """8..14 points: OpenCV's findFundamentalMat takes the LMedS registrator; F, mask and the
+    winning hypothesis equal the oracle's restatement of it."""
+    o = det_math
+    sc = synth.two_view_scene(n, seed=900 + 7 * n + seed, outlier_frac=0.2 if seed else 0.0, noise_px=0.3)
+    F, mask, info = ransac.find_fundamental_ransac(sc["p1"], sc["p2"], 1.0, 0.99, 200)
+    oF, omask, oinfo = o.find_fundamental_mat(sc["p1"], sc["p2"], 1.0, 0.99, 200)
+    assert (info.best_iter, info.best_model, info.max_good, info.niters) == tuple(int(v) for v in oinfo)
+    assert np.array_equal(mask, omask)
+    assert (F is None) == (oF is None)
+    if F is not None:
+        assert np.array_equal(F, oF) and abs(np.linalg.det(F)) < 1e-6 * np.abs(F).max() ** 3 + 1e-12
+    # and through the reference-shaped entry points
+    F2, mask2 = geometry.calc_fundamental_mat(sc["p1"], sc["p2"])
+    F3, mask3 = cv2_shim.findFundamentalMat(sc["p1"], sc["p2"], cv2_shim.RANSAC, 1.0, 0.99, 200)
+    assert np.array_equal(mask3, omask) and (F3 is None) == (oF is None)
+    assert mask2.shape == (n, 1)
+
+
+def test_lmeds_median_kernel_orders_like_int_keys(dev):
+    """rank N/2 under the int reinterpretation of the f32 errors, +Inf for models that do not exist, and
+    a clear error beyond 64 points."""
+    from visual_odometry_amd import _lib
+    rng = np.random.default_rng(4)
+    sc = synth.two_view_scene(64, seed=31)
+    for n in (1, 2, 8, 13, 14, 33, 64):
+        pts4 = np.concatenate([sc["p1"][:n], sc["p2"][:n]], 1).astype(np.float32)
+        models = rng.normal(size=(40, 9)); models[3] = np.nan; models[5] = 0.0
+        valid = np.ones(40, np.uint8); valid[7] = 0
+        med = ops.lmeds_median_fund(_d(models, dev), _d(pts4, dev), _d(valid, dev)).cpu().numpy()
+        import oracle
+        for h in range(40):
+            if not valid[h]:
+                assert np.isposinf(med[h]); continue
+            with np.errstate(all="ignore"):
+                e = oracle.fund_error(models[h], pts4[:, :2], pts4[:, 2:])
+            want = np.sort(e.view(np.int32))[n // 2]
+            assert med[h:h + 1].view(np.int32)[0] == want, (n, h)
+    with pytest.raises(_lib.VoError):
+        ops.lmeds_median_fund(_d(rng.normal(size=(4, 9)), dev), _d(np.zeros((65, 4), np.float32), dev))
+
+
 def test_find_fundamental_small_inputs(dev):
     sc = synth.two_view_scene(20, seed=3)
     assert cv2_shim.findFundamentalMat(sc["p1"][:6], sc["p2"][:6], cv2_shim.RANSAC, 1.0, 0.99, 10) == (None, None)
     F, mask = cv2_shim.findFundamentalMat(sc["p1"][:7], sc["p2"][:7], cv2_shim.RANSAC, 1.0, 0.99, 10)
     assert F.shape[1] == 3 and F.shape[0] in (3, 6, 9) and mask.sum() == 7
-    with pytest.raises(NotImplementedError):
-        cv2_shim.findFundamentalMat(sc["p1"][:10], sc["p2"][:10], cv2_shim.RANSAC, 1.0, 0.99, 10)
+    F, mask = cv2_shim.findFundamentalMat(sc["p1"][:10], sc["p2"][:10], cv2_shim.RANSAC, 1.0, 0.99, 10)   # LMedS (A.3)
+    assert mask.shape == (10, 1) and (F is None or F.shape == (3, 3))
 
 
 @pytest.mark.parametrize("n,thr,iters,seed", [(1500, 1.0, 200, 1), (300, 0.5, 500, 2)])

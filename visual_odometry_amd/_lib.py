@@ -52,6 +52,7 @@ _SIGNATURES = {
     "vo_triangulate": (_i, [C.POINTER(_d), C.POINTER(_d), _vp, _vp, _i, _vp, _vp]),
     "vo_pose_tail_batch": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_d), _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vo_epnp_batch": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_d), _i, _i, _vp, _vp, _vp]),
+    "vo_lmeds_median_fund": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "vo_ransac_workspace_bytes": (_sz, [_i, _i, _i]),
     "vo_ransac_batch": (_i, [_i, _vp, _i, _vp, _vp, C.POINTER(_d), _i, _vp, _i, _f, _d, _i, _i, _vp, _vp, _vp, _vp,
                              _vp, _sz, _vp]),

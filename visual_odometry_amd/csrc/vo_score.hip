@@ -482,6 +482,32 @@ void mask_best_kernel(const MaskArgs a)
     a.mask[(size_t)b * a.N + i] = m;
 }
 
+// LMedS ranking (OpenCV's LMeDSPointSetRegistrator, used by findFundamentalMat for 8..14 points): per
+// model the element of rank N/2 among its f32 errors ordered as their int reinterpretation (what
+// std::nth_element over errf.ptr<int>() yields).  Thread per model, N <= kLmedsMaxPoints.
+constexpr int kLmedsMaxPoints = 64;
+
+__global__ __launch_bounds__(64)
+void lmeds_median_fund_kernel(const double* __restrict__ models, const uint8_t* __restrict__ valid, int H,
+                              const float4* __restrict__ pts, int N, float* __restrict__ medians)
+{
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    if (valid && !valid[h]) { medians[h] = __builtin_huge_valf(); return; }
+    double F[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) F[k] = models[(size_t)h * 9 + k];
+    int key[kLmedsMaxPoints];
+    for (int i = 0; i < N; ++i) {                       // insertion sort of the int keys
+        const float4 v = pts[i];
+        const int e = __float_as_int(fund_err(F, v.x, v.y, v.z, v.w));
+        int j = i;
+        for (; j > 0 && key[j - 1] > e; --j) key[j] = key[j - 1];
+        key[j] = e;
+    }
+    medians[h] = __int_as_float(key[N / 2]);
+}
+
 int pick_chunk(int H, int N, int batch)
 {
     const long mblocks = (long)vo_ceil_div(H, kThreads) * batch;
@@ -621,6 +647,20 @@ extern "C" int vo_mask_pnp(const double* model, const float* obj, const float* i
                  "vo_mask_pnp: null/unaligned pointer");
     hipLaunchKernelGGL(mask_pnp_kernel, dim3(vo_ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, model, obj,
                        (const float2*)img, N, K4_host[0], K4_host[1], K4_host[2], K4_host[3], thr2, mask);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}
+
+extern "C" int vo_lmeds_median_fund(const double* models, const uint8_t* valid, int H, const float* pts, int N,
+                                    float* medians, void* stream)
+{
+    VO_CHECK_ARG(H >= 0 && N >= 1 && N <= kLmedsMaxPoints, VO_EINVAL,
+                 "vo_lmeds_median_fund: N = %d outside 1..%d (LMedS serves the 8..14 point case)", N, kLmedsMaxPoints);
+    if (H == 0) return VO_OK;
+    VO_CHECK_ARG(models && pts && medians && ((uintptr_t)pts & 15) == 0, VO_EINVAL,
+                 "vo_lmeds_median_fund: null/unaligned pointer");
+    hipLaunchKernelGGL(lmeds_median_fund_kernel, dim3(vo_ceil_div(H, 64)), dim3(64), 0, (hipStream_t)stream, models,
+                       valid, H, (const float4*)pts, N, medians);
     VO_LAUNCH_CHECK();
     return VO_OK;
 }

@@ -417,3 +417,25 @@ def epnp_batch(obj: torch.Tensor, img: torch.Tensor, mask: torch.Tensor, K, n_de
     _lib.check(_lib.load().vo_epnp_batch(_ptr(obj), _ptr(img), _ptr(mask), _ptr(n_dev), _ptr(result), _K4(K), N, B,
                                          _ptr(Rt), _ptr(ok), _stream()), "vo_epnp_batch")
     return Rt, ok
+
+
+def lmeds_median_fund(models: torch.Tensor, pts4: torch.Tensor, valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """models (H,9) f64, pts4 (N<=64,4) f32 -> (H,) f32 medians of the epipolar errors (rank N//2; +Inf where
+    valid is 0): the ranking of OpenCV's LMedS registrator."""
+    _lib.require_device()
+    models = _dev(models, torch.float64, "models").reshape(-1, 9)
+    pts4 = _dev(pts4, torch.float32, "pts4").reshape(-1, 4)
+    H = models.shape[0]
+    if valid is not None:
+        valid = _dev(valid, torch.uint8, "valid").reshape(-1)
+        if valid.numel() != H:
+            raise _lib.VoError("lmeds_median_fund: valid must have one flag per model")
+    med = torch.empty((H,), dtype=torch.float32, device=models.device)
+    _lib.check(_lib.load().vo_lmeds_median_fund(_ptr(models), _ptr(valid), H, _ptr(pts4), pts4.shape[0], _ptr(med),
+                                                _stream()), "vo_lmeds_median_fund")
+    return med
+
+
+def update_num_iters(p: float, ep: float, model_points: int, max_iters: int) -> int:
+    """OpenCV's RANSACUpdateNumIters (host helper of the library)."""
+    return int(_lib.load().vo_host_update_num_iters(float(p), float(ep), int(model_points), int(max_iters)))

@@ -43,6 +43,40 @@ def _h2d(a: np.ndarray) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------- fundamental
+def _find_fundamental_lmeds(pts4: np.ndarray, confidence: float, max_iters: int, info: "RansacInfo"):
+    """8..14 points: OpenCV 4.6.0's findFundamentalMat runs its LMedS registrator even when RANSAC was
+    asked for.  The iteration count is fixed up front (outlier ratio 0.45 assumed, at
+    least 3), models are ranked by the median of their errors (first strictly smallest wins), inliers
+    lie within sigma = 2.5 * 1.4826 * (1 + 5/(n-7)) * sqrt(median), at least 0.001."""
+    n = pts4.shape[0]
+    if confidence < _DBL_EPS or confidence > 1 - _DBL_EPS:
+        confidence = 0.99
+    niters = max(ops.update_num_iters(confidence, 0.45, 7, max_iters), 3)
+    info.niters = niters
+    mask0 = np.zeros((n, 1), np.uint8)
+    subsets = ops.gen_subsets(n, 7, niters, pts4)
+    info.n_generated = len(subsets)
+    if len(subsets) == 0:
+        return None, mask0, info
+    pts_d = _h2d(pts4)
+    models, nm = ops.solve_7pt(_h2d(subsets), pts_d)                      # (h,3,9), (h,)
+    valid = (torch.arange(3, device=nm.device, dtype=torch.int32)[None, :] < nm[:, None]).to(torch.uint8)
+    med = ops.lmeds_median_fund(models.reshape(-1, 9), pts_d, valid.reshape(-1)).cpu().numpy().astype(np.float64)
+    best, min_median = -1, float(np.finfo(np.float64).max)
+    for i, m in enumerate(med):                                           # "median < minMedian", in order
+        if m < min_median:
+            best, min_median = i, float(m)
+    if best < 0:
+        return None, mask0, info
+    sigma = max(2.5 * 1.4826 * (1 + 5.0 / (n - 7)) * float(np.sqrt(min_median)), 0.001)
+    model = models.reshape(-1, 9)[best]
+    mask = ops.mask_fund(model, pts_d, sigma).cpu().numpy().reshape(n, 1)
+    info.best_iter, info.best_model, info.max_good = best // 3, best % 3, int(mask.sum())
+    if info.max_good < 7:
+        return None, mask, info
+    return model.reshape(3, 3).cpu().numpy(), mask, info
+
+
 def find_fundamental_ransac(points1, points2, threshold: float, confidence: float, max_iters: int,
                             group=None) -> Tuple[Optional[np.ndarray], Optional[np.ndarray], RansacInfo]:
     """cv2.findFundamentalMat(p1, p2, cv2.RANSAC, threshold, confidence, max_iters).
@@ -66,9 +100,7 @@ def find_fundamental_ransac(points1, points2, threshold: float, confidence: floa
             return None, np.ones((n, 1), np.uint8), info
         return models[0, :k].reshape(3 * k, 3).cpu().numpy(), np.ones((n, 1), np.uint8), info
     if n < 15:
-        raise NotImplementedError(
-            "findFundamentalMat with 8..14 points runs LMedS in OpenCV 4.6.0, which this library "
-            "does not provide (the reference never reaches it: SURVEY.md A.3)")
+        return _find_fundamental_lmeds(pts4, confidence, max_iters, info)
     if threshold <= 0:
         threshold = 3
     if confidence < _DBL_EPS or confidence > 1 - _DBL_EPS:
