@@ -298,3 +298,22 @@ def test_pose_tail_against_reference_helpers(oracle_mod):
             assert np.allclose(r, R, atol=1e-12) and np.allclose(u, u3, atol=1e-12)
         assert np.allclose(hom_inv(T), Tinv, atol=1e-15) and np.allclose(oracle_mod.hom_inv(T), Tinv, atol=1e-15)
         assert np.allclose(hom_inv(T) @ T, np.eye(4), atol=1e-12)
+
+
+def test_oracle_lmeds_small_point_sets(oracle_mod):
+    """8..14 points go through the LMedS restatement: on noise-free data the winner has a vanishing
+    median, (nearly) every point is an inlier of the sigma floor (0.001 px: f32-rounded coordinates through a
+    minimal solve can miss it) and F satisfies the epipolar constraint; the
+    iteration count is the fixed one (outlier ratio 0.45), never the RANSAC one."""
+    for n in (8, 10, 14):
+        sc = synth.two_view_scene(n, seed=60 + n, noise_px=0.0, outlier_frac=0.0)
+        F, mask, info = oracle_mod.find_fundamental_mat(sc["p1"], sc["p2"], 1.0, 0.99, 500)
+        assert F is not None and mask.sum() >= 7
+        assert info[3] == max(oracle_mod.update_num_iters(0.99, 0.45, 7, 500), 3)
+        x1 = np.c_[sc["p1"].astype(np.float64), np.ones(n)]; x2 = np.c_[sc["p2"].astype(np.float64), np.ones(n)]
+        res = np.abs(np.einsum("ni,ij,nj->n", x2, F, x1)) / np.linalg.norm(F)
+        assert res.max() < 1e-3 and abs(np.linalg.det(F)) < 1e-9 * np.abs(F).max() ** 3 + 1e-15
+    # 15 points: back on the RANSAC path (info[3] then is the adaptive count)
+    sc = synth.two_view_scene(15, seed=5, noise_px=0.0, outlier_frac=0.0)
+    F, mask, info = oracle_mod.find_fundamental_mat(sc["p1"], sc["p2"], 1.0, 0.99, 500)
+    assert F is not None and info[3] < 500
