@@ -312,7 +312,9 @@ def test_oracle_lmeds_small_point_sets(oracle_mod):
         assert info[3] == max(oracle_mod.update_num_iters(0.99, 0.45, 7, 500), 3)
         x1 = np.c_[sc["p1"].astype(np.float64), np.ones(n)]; x2 = np.c_[sc["p2"].astype(np.float64), np.ones(n)]
         res = np.abs(np.einsum("ni,ij,nj->n", x2, F, x1)) / np.linalg.norm(F)
-        assert res.max() < 1e-3 and abs(np.linalg.det(F)) < 1e-9 * np.abs(F).max() ** 3 + 1e-15
+        # (every root of a 7-point sample fits its 7 points, so the first model already has a zero median;
+        # it need not be the scene's F, only a majority of the points must lie on it)
+        assert np.sort(res)[n // 2] < 1e-3 and abs(np.linalg.det(F)) < 1e-9 * np.abs(F).max() ** 3 + 1e-15
     # 15 points: back on the RANSAC path (info[3] then is the adaptive count)
     sc = synth.two_view_scene(15, seed=5, noise_px=0.0, outlier_frac=0.0)
     F, mask, info = oracle_mod.find_fundamental_mat(sc["p1"], sc["p2"], 1.0, 0.99, 500)
