@@ -149,6 +149,33 @@ def end_to_end_cases():
     save("end_to_end.npz", **out)
 
 
+def pose_cases():
+    """the widened rows: cv.triangulatePoints, the disambiguation chain, the EPnP refit and the LMedS
+    branch of findFundamentalMat, in det-math mode (hypot evaluated as sqrt(a*a+b*b), like the device)."""
+    o.set_det_math(True)
+    out = {}
+    sc = synth.two_view_scene(300, seed=501, outlier_frac=0.1)
+    K = sc["K"]
+    P1, P2 = K @ np.eye(3, 4), K @ np.c_[sc["R"], sc["t"]]
+    x1, x2 = sc["p1"].astype(np.float64), sc["p2"].astype(np.float64)
+    out.update(tri_P1=P1, tri_P2=P2, tri_x1=x1, tri_x2=x2, tri_X=o.triangulate_points(P1, P2, x1.T, x2.T).T)
+    F, mask, _ = o.find_fundamental_mat(sc["p1"], sc["p2"], 1.0, 0.999, 200)
+    Rs, u3 = o.decompose_essential_matrix(K.T @ F @ K)
+    sel = mask.ravel() == 1
+    T, P, m = o.disambiguate_relative_pose(Rs, u3, np.c_[x1[sel], np.ones(sel.sum())].T, np.c_[x2[sel], np.ones(sel.sum())].T, K, K)
+    out.update(tail_K=K, tail_F=F, tail_mask=mask, tail_p1=sc["p1"], tail_p2=sc["p2"], tail_T=T, tail_P=P, tail_keep=m)
+    ps = synth.pnp_scene(500, seed=502, outlier_frac=0.0)
+    ok, R, t = o.epnp(ps["obj"].astype(np.float64), ps["img"].astype(np.float64), ps["K"])
+    out.update(epnp_obj=ps["obj"], epnp_img=ps["img"], epnp_K=ps["K"], epnp_R=R, epnp_t=t)
+    for n in (9, 13):
+        sc = synth.two_view_scene(n, seed=503 + n, outlier_frac=0.2)
+        F, mask, info = o.find_fundamental_mat(sc["p1"], sc["p2"], 1.0, 0.99, 200)
+        out.update({f"lmeds{n}_p1": sc["p1"], f"lmeds{n}_p2": sc["p2"], f"lmeds{n}_F": F if F is not None else np.zeros((0, 3)),
+                    f"lmeds{n}_mask": mask, f"lmeds{n}_info": info})
+    o.set_det_math(False)
+    save("pose.npz", **out)
+
+
 def ref_helper_cases():
     ref_src = "/root/reference/src"
     if not os.path.isdir(ref_src):
@@ -175,4 +202,7 @@ def ref_helper_cases():
 
 if __name__ == "__main__":
     o.build()
-    knn_cases(); rng_cases(); scoring_cases(); replay_cases(); end_to_end_cases(); ref_helper_cases()
+    if len(sys.argv) > 1 and sys.argv[1] == "pose":        # only the fixtures added later
+        pose_cases()
+        sys.exit(0)
+    knn_cases(); rng_cases(); scoring_cases(); replay_cases(); end_to_end_cases(); pose_cases(); ref_helper_cases()

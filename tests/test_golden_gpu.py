@@ -103,3 +103,33 @@ def test_pose_tail_end_to_end(oracle_mod, dev, capsys):
         assert P_world.shape[0] > 300
     finally:
         params.which_dataset(0)
+
+
+def test_pose_golden(dev):
+    """tests/golden/pose.npz: triangulation bit for bit, the disambiguation chain and the EPnP refit to
+    1e-6, the LMedS branch bit for bit."""
+    from visual_odometry_amd import ransac
+    g = load("pose.npz")
+    X = ops.triangulate(g["tri_P1"], g["tri_P2"], _d(g["tri_x1"], dev), _d(g["tri_x2"], dev)).cpu().numpy()
+    assert np.array_equal(X, g["tri_X"])
+    n = len(g["tail_p1"])
+    pts4 = np.concatenate([g["tail_p1"], g["tail_p2"]], 1).astype(np.float32)
+    out = ops.pose_tail_batch(_d(g["tail_F"].reshape(1, 9), dev), _d(g["tail_mask"].reshape(1, n), dev), _d(pts4[None], dev),
+                              g["tail_K"], 50.0)
+    sel = g["tail_mask"].ravel() == 1
+    keep = out["keep"][0].cpu().numpy().astype(bool)
+    full = np.zeros(n, bool); full[np.nonzero(sel)[0][g["tail_keep"]]] = True
+    assert np.array_equal(keep, full)
+    assert np.allclose(out["T"][0].cpu().numpy(), g["tail_T"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(out["X"][0].cpu().numpy()[keep], g["tail_P"], rtol=1e-6, atol=1e-8)
+    m = len(g["epnp_obj"])
+    Rt, ok = ops.epnp_batch(_d(g["epnp_obj"][None], dev), _d(g["epnp_img"][None], dev), _d(np.ones((1, m), np.uint8), dev), g["epnp_K"])
+    assert int(ok[0]) == 1
+    Rt = Rt[0].cpu().numpy()
+    assert np.allclose(Rt[:9].reshape(3, 3), g["epnp_R"], rtol=1e-6, atol=1e-8) and np.allclose(Rt[9:], g["epnp_t"].ravel(), rtol=1e-6, atol=1e-8)
+    for k in (9, 13):
+        F, mask, info = ransac.find_fundamental_ransac(g[f"lmeds{k}_p1"], g[f"lmeds{k}_p2"], 1.0, 0.99, 200)
+        assert np.array_equal(mask, g[f"lmeds{k}_mask"])
+        assert (info.best_iter, info.best_model, info.max_good, info.niters) == tuple(int(v) for v in g[f"lmeds{k}_info"])
+        gF = g[f"lmeds{k}_F"]
+        assert (F is None and gF.shape[0] == 0) or np.array_equal(F, gF)
