@@ -368,39 +368,52 @@ void knn2_merge_kernel(const int4* __restrict__ partial, const int32_t* __restri
     *(int2*)(d2 + o) = make_int2(r.j1 >= 0 ? qn - r.k1 : INT_MAX, r.j2 >= 0 ? qn - r.k2 : INT_MAX);
 }
 
-// f32 (integers 0..255) -> int8 (value-128) + squared norm of the int8 row; 32 lanes per row
+// f32 (integers 0..255) -> int8 (value-128) + squared norm of the int8 row; 32 lanes per row, four rows
+// per lane group with their loads issued together (the kernel is a pure HBM stream: 512 B in, 132 B out
+// per row, and one 16-byte load per thread in flight does not cover the latency)
+constexpr int kDescRowsPerGroup = 4;
 __global__ __launch_bounds__(256)
 void desc_f32_to_i8_kernel(const float* __restrict__ desc, int n, int8_t* __restrict__ out,
                            int32_t* __restrict__ norm, int32_t* __restrict__ flags)
 {
-    const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
-    int bad = 0, s = 0, su = 0;
-    if (row < n) {
-        const float4 v = *(const float4*)(desc + (size_t)row * kDim + 4 * l);
-        const float f[4] = {v.x, v.y, v.z, v.w};
-        char4 o;
+    const int row0 = (blockIdx.x * 8 + (threadIdx.x >> 5)) * kDescRowsPerGroup, l = threadIdx.x & 31;
+    float4 v[kDescRowsPerGroup];
+#pragma unroll
+    for (int r = 0; r < kDescRowsPerGroup; ++r) {
+        const int row = row0 + r < n ? row0 + r : n - 1;
+        v[r] = *(const float4*)(desc + (size_t)row * kDim + 4 * l);
+    }
+    int bad = 0;
+#pragma unroll
+    for (int r = 0; r < kDescRowsPerGroup; ++r) {
+        const int row = row0 + r;
+        const float f[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+        int s = 0, su = 0;
         signed char ov[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float x = f[k];
-            if (!(x >= 0.f && x <= 255.f) || x != truncf(x)) bad = VO_DESC_BAD_VALUE;
+            if (row < n && (!(x >= 0.f && x <= 255.f) || x != truncf(x))) bad = VO_DESC_BAD_VALUE;
             const int u = (int)fminf(fmaxf(x, 0.f), 255.f);
             const int c = u - 128;
             ov[k] = (signed char)c;
             s += c * c;
             su += u * u;
         }
-        o.x = ov[0]; o.y = ov[1]; o.z = ov[2]; o.w = ov[3];
-        *(char4*)(out + (size_t)row * kDim + 4 * l) = o;
-    }
+        if (row < n) {
+            char4 o;
+            o.x = ov[0]; o.y = ov[1]; o.z = ov[2]; o.w = ov[3];
+            *(char4*)(out + (size_t)row * kDim + 4 * l) = o;
+        }
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) {
-        s += __shfl_xor(s, off);
-        su += __shfl_xor(su, off);
-    }
-    if (row < n && l == 0) {
-        norm[row] = s;
-        if (su > (1 << 20)) bad |= VO_DESC_BAD_NORM;
+        for (int off = 16; off > 0; off >>= 1) {
+            s += __shfl_xor(s, off);
+            su += __shfl_xor(su, off);
+        }
+        if (row < n && l == 0) {
+            norm[row] = s;
+            if (su > (1 << 20)) bad |= VO_DESC_BAD_NORM;
+        }
     }
     if (bad) atomicOr(flags, bad);
 }
@@ -522,7 +535,7 @@ extern "C" int vo_desc_f32_to_i8(const float* desc, int n, int8_t* out_i8, int32
     VO_CHECK_ARG(desc && out_i8 && out_norm && flags, VO_EINVAL, "vo_desc_f32_to_i8: null pointer");
     VO_CHECK_ARG(((uintptr_t)desc & 15) == 0 && ((uintptr_t)out_i8 & 3) == 0, VO_EINVAL,
                  "vo_desc_f32_to_i8: desc must be 16-byte aligned");
-    hipLaunchKernelGGL(desc_f32_to_i8_kernel, dim3(vo_ceil_div(n, 8)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(desc_f32_to_i8_kernel, dim3(vo_ceil_div(n, 8 * kDescRowsPerGroup)), dim3(256), 0, (hipStream_t)stream,
                        desc, n, out_i8, out_norm, flags);
     VO_LAUNCH_CHECK();
     return VO_OK;
