@@ -74,6 +74,38 @@ def step(ps: PairSet):
                                      workspace=ps.ws, wait_pnp=False)
 
 
+def drop_in_latency():
+    """Wall clock of the reference-shaped single-pair entry points (host numpy in, host numpy out:
+    H2D of the inputs, kernels, stream sync, D2H of the results) on one cfg4-sized frame pair --
+    SURVEY.md 8d asks for this beside the device-resident rate; it is not part of `value`."""
+    import contextlib, io
+    from visual_odometry_amd import cv2_shim
+    from visual_odometry_amd.features import match_features_indices
+    fp = synth.frame_pair(NQ, NT, seed=77, K=K, size=SIZE)
+    out = {}
+    def timed(name, fn, reps=3):
+        fn()                                                  # warm-up (allocations, first-touch)
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        out[name + "_ms"] = float(np.median(ts))
+        return r
+    with contextlib.redirect_stdout(io.StringIO()):
+        qi, ti = timed("match_features_8192x8192", lambda: match_features_indices(fp["q"], fp["t"], RATIO))
+        p1, p2 = fp["kp_q"][qi], fp["kp_t"][ti]
+        timed("findFundamentalMat_4096_iters", lambda: cv2_shim.findFundamentalMat(p1, p2, cv2_shim.RANSAC, F_THR, F_CONF, H))
+        timed("solvePnPRansac_4096_iters", lambda: cv2_shim.solvePnPRansac(fp["xyz_q"][qi], p2, K, None, iterationsCount=H,
+                                                                         reprojectionError=P_THR, confidence=P_CONF,
+                                                                         flags=cv2_shim.SOLVEPNP_P3P))
+    out["matches"] = int(len(qi))
+    out["note"] = ("median of 3 calls each, one frame pair, host arrays in and out (PCIe both ways, one stream sync per call); "
+                   "the batched device-resident pipeline is what `value` measures")
+    return out
+
+
 def cpu_baseline(max_seconds: float = 25.0):
     """The oracle (CPU restatement of the OpenCV routines; OpenCV itself is absent) on the same
     workload, a bounded number of frame pairs."""
@@ -273,6 +305,7 @@ def main():
         "device": prop.name, "cus": cus,
     }
     if rank == 0:
+        line["drop_in_latency"] = drop_in_latency() if world == 1 else None
         line["cpu_baseline"] = cpu_baseline() if (world == 1 and not args.no_cpu) else None
         print(json.dumps(line), flush=True)
     if dist:
