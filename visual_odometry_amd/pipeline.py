@@ -50,9 +50,10 @@ _side = {}
 def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
     if key not in _side:
-        # high priority: the chain's kernels are small and would otherwise starve behind the F scoring
-        # launch that fills the GPU from the main stream
-        _side[key] = torch.cuda.Stream(device=dev, priority=-1)
+        # default priority on purpose: a high-priority stream changed nothing in the measured overlap, and
+        # with an RCCL communicator alive in the process (bench.py under torch.distributed.run) the
+        # cross-stream waits of the chain never completed on it
+        _side[key] = torch.cuda.Stream(device=dev)
     return _side[key]
 
 
@@ -94,7 +95,7 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
     """desc_* (B,n,128) f32 integer-valued, kp_* (B,n,2) f32, xyz_q (B,nq,3) f32 landmarks of the query
     keypoints (enables the PnP run when p_iters > 0).  first_block_*: see ops.ransac_batch (0 = evaluate all
     iterations at once).  Everything is enqueued on the current stream, except the PnP chain (P3P RANSAC +
-    EPnP refit), which runs on a high-priority side stream; with wait_pnp=True (default) the current
+    EPnP refit), which runs on a side stream; with wait_pnp=True (default) the current
     stream waits for it before returning, with wait_pnp=False the caller does (`result.wait_pnp()`), which
     lets the small, latency-bound PnP kernels of one batch fill the gaps of the next batch's big ones.
 
