@@ -60,3 +60,17 @@ if "sabl2" in os.environ.get("VO_HIP_LIB", ""):
     bad = np.nonzero(own > 0)[0][:5]
     for b_ in bad:
         print("bad model", b_, own[b_], F[b_])
+# early-exit statistics: a wave of 64 consecutive models skips the second denominator for a correspondence
+# when every lane is already "sure outlier" against den2 alone
+notout = ~(d2 * d2 > t * den2 * (1 + 2.0 ** -16))
+print("not-out-by-den2 fraction", notout.mean(), "inlier fraction", inl.mean())
+G = (len(F) // 64) * 64
+w = notout[:G].reshape(-1, 64, notout.shape[1]).any(1)
+print("wave x correspondence that needs the full test:", w.mean())
+per_model = notout.mean(1)
+print("per-model not-out fraction: median", np.median(per_model), "p90", np.quantile(per_model, 0.9), "p99", np.quantile(per_model, 0.99), "max", per_model.max())
+# the same with the correspondences across the lanes (score_fund_kernel): 64 consecutive correspondences, one model
+Gp = (notout.shape[1] // 64) * 64
+wp = notout[:, :Gp].reshape(len(F), -1, 64).any(2)
+print("model x 64-correspondence group that needs the full test:", wp.mean())
+f32amb = ~(inl | out)      # f64-filter ambiguity, a lower bound for the f32 tier
