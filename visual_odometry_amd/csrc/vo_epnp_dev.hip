@@ -146,7 +146,10 @@ struct EpnpArgs {
     double fu, fv, uc, vc;
 };
 
-__global__ __launch_bounds__(kThreads)
+// Two waves per SIMD must fit: left alone the compiler takes all 512 registers of a SIMD (256 + 256
+// accumulation registers as spill space) for the single-thread algebra, a workgroup then owns its whole
+// CU and every kernel of the other stream waits for it (measured: 0.2 ms per 256-pair step).
+__global__ __launch_bounds__(kThreads, 2)
 void epnp_batch_kernel(const EpnpArgs a)
 {
     __shared__ double sh[kWaves * 78];

@@ -48,8 +48,9 @@ def thr2_of(threshold: float) -> float:
 
 
 # ------------------------------------------------------------------------------- matching
-def desc_to_i8(desc: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """(n,128) f32 integer-valued descriptors -> (int8 rows, int32 squared norms, int32 flag word)."""
+def desc_to_i8(desc: torch.Tensor, flags: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(n,128) f32 integer-valued descriptors -> (int8 rows, int32 squared norms, int32 flag word).
+    `flags` (1,) int32, already zero, may be passed in (the kernel only ORs into it)."""
     _lib.require_device()
     desc = _dev(desc, torch.float32, "desc")
     if desc.ndim != 2 or desc.shape[1] != 128:
@@ -57,7 +58,10 @@ def desc_to_i8(desc: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Te
     n = desc.shape[0]
     out = torch.empty((n, 128), dtype=torch.int8, device=desc.device)
     norm = torch.empty((n,), dtype=torch.int32, device=desc.device)
-    flags = torch.zeros((1,), dtype=torch.int32, device=desc.device)
+    if flags is None:
+        flags = torch.zeros((1,), dtype=torch.int32, device=desc.device)
+    else:
+        flags = _dev(flags, torch.int32, "flags")
     _lib.check(_lib.load().vo_desc_f32_to_i8(_ptr(desc), n, _ptr(out), _ptr(norm), _ptr(flags), _stream()),
                "vo_desc_f32_to_i8")
     return out, norm, flags

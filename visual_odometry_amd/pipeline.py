@@ -104,8 +104,9 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
     than 15 (F) / 5 (PnP) matches get no model (the reference's cv2 calls switch algorithm or fail
     there)."""
     B, nq, nt = desc_q.shape[0], desc_q.shape[1], desc_t.shape[1]
-    qi8, qn, _ = ops.desc_to_i8(desc_q.reshape(B * nq, 128))
-    ti8, tn, _ = ops.desc_to_i8(desc_t.reshape(B * nt, 128))
+    flags = torch.zeros((2,), dtype=torch.int32, device=desc_q.device)       # one fill for both conversions
+    qi8, qn, _ = ops.desc_to_i8(desc_q.reshape(B * nq, 128), flags[0:1])
+    ti8, tn, _ = ops.desc_to_i8(desc_t.reshape(B * nt, 128), flags[1:2])
     do_pnp = p_iters > 0 and xyz_q is not None
     ws_k, ws_f, ws_p = _split_workspace(workspace, nq, nt, f_iters, p_iters if do_pnp else 0, B)
     idx, d2 = ops.knn2(qi8.reshape(B, nq, 128), qn.reshape(B, nq), ti8.reshape(B, nt, 128), tn.reshape(B, nt), ws_k)
