@@ -164,10 +164,13 @@ def models_scored(nm, result, first):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=256, help="frame pairs per GPU per step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-latency", action="store_true",
+                    help="skip the single-pair drop_in_latency leg (profiling runs: keeps rocprofv3's per-kernel "
+                         "averages to the launches of the steps)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -305,7 +308,7 @@ def main():
         "device": prop.name, "cus": cus,
     }
     if rank == 0:
-        line["drop_in_latency"] = drop_in_latency() if world == 1 else None
+        line["drop_in_latency"] = drop_in_latency() if (world == 1 and not args.no_latency) else None
         line["cpu_baseline"] = cpu_baseline() if (world == 1 and not args.no_cpu) else None
         print(json.dumps(line), flush=True)
     if dist:

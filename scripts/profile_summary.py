@@ -2,7 +2,7 @@
 """Per-step table from a rocprofv3 kernel trace of bench.py (scripts/gpu_profile.sh).
 usage: profile_summary.py gpurun_out/prof_<tag>/bench_kernel_trace.csv [pairs]
 A step starts at a knn2_partial_kernel launch over `pairs` problems (grid z); the window runs from the
-third such launch (two warm-up steps) to the last one, so the PnP tail of every step inside it is seen."""
+fourth such launch (three warm-up steps) to the last one, so the PnP tail of every step inside it is seen."""
 import collections, csv, re, sys
 
 path = sys.argv[1]
@@ -11,8 +11,8 @@ rows = list(csv.DictReader(open(path)))
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 starts = sorted(r["s"] for r in rows if "knn2_partial_kernel" in r["Kernel_Name"] and int(r["Grid_Size_Z"]) == pairs)
-assert len(starts) >= 4, "expected at least two warm-up and two timed steps"
-t0, t1, nsteps = starts[2], starts[-1], len(starts) - 3
+assert len(starts) >= 5, "expected three warm-up and at least two timed steps"
+t0, t1, nsteps = starts[3], starts[-1], len(starts) - 4
 
 
 def short(name):
