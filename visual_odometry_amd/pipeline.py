@@ -47,8 +47,10 @@ class PairBatchResult:
 _side = {}
 
 
-def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+def _side_stream(dev: torch.device, main: "torch.cuda.Stream") -> "torch.cuda.Stream":
+    """The PnP chain's stream: one per (device, caller's stream), so that callers that run several
+    batches concurrently on streams of their own do not serialise their PnP chains on one."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), main.cuda_stream)
     if key not in _side:
         # default priority on purpose: a high-priority stream changed nothing in the measured overlap, and
         # with an RCCL communicator alive in the process (bench.py under torch.distributed.run) the
@@ -118,7 +120,7 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
     main = torch.cuda.current_stream()
     pnp_out = None
     if do_pnp:
-        side = _side_stream(desc_q.device)
+        side = _side_stream(desc_q.device, main)
         side.wait_stream(main)
         for t in (c["obj"], c["img"], n):
             t.record_stream(side)                  # allocated on the caller's stream, read on the side stream
