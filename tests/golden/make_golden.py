@@ -197,12 +197,28 @@ def ref_helper_cases():
         Es.append(E); Rs.append(R); u3s.append(u3)
         T = np.eye(4); T[:3, :3] = sc["R"]; T[:3, 3] = rng.normal(size=3) * 5
         Ts.append(T); Tinvs.append(hom_inv(T))
-    save("ref_helpers.npz", E=np.array(Es), R=np.array(Rs), u3=np.array(u3s), T=np.array(Ts), Tinv=np.array(Tinvs))
+    # the reference's own numpy DLT triangulation (src/utils/linear_triangulation.py) on a noise-free scene:
+    # same null vector as cv.triangulatePoints' 4-row system there, so it pins the triangulation of the
+    # pose tail against reference code (dehomogenised, as the reference returns it)
+    from utils.linear_triangulation import linearTriangulation                   # reference, pure numpy
+    sc = synth.two_view_scene(40, K=synth.K_KITTI, size=synth.IMAGE_SIZE["kitti"], seed=808, noise_px=0.0, outlier_frac=0.0)
+    Kk = synth.K_KITTI
+    M1 = Kk @ np.hstack([np.eye(3), np.zeros((3, 1))])
+    M2 = Kk @ np.hstack([sc["R"], sc["t"].reshape(3, 1)])
+    proj = lambda M, X: (lambda q: (q[:2] / q[2]).T)(M @ np.vstack([X.T, np.ones((1, X.shape[0]))]))
+    p1, p2 = proj(M1, sc["X"]), proj(M2, sc["X"])                                # exact f64 projections
+    h = lambda p: np.vstack([p.T, np.ones((1, p.shape[0]))])
+    tri_P = linearTriangulation(h(p1), h(p2), M1, M2)
+    save("ref_helpers.npz", E=np.array(Es), R=np.array(Rs), u3=np.array(u3s), T=np.array(Ts), Tinv=np.array(Tinvs),
+         tri_M1=M1, tri_M2=M2, tri_p1=p1, tri_p2=p2, tri_P=tri_P)
 
 
 if __name__ == "__main__":
     o.build()
     if len(sys.argv) > 1 and sys.argv[1] == "pose":        # only the fixtures added later
         pose_cases()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ref":         # only the fixtures made by importing reference helpers
+        ref_helper_cases()
         sys.exit(0)
     knn_cases(); rng_cases(); scoring_cases(); replay_cases(); end_to_end_cases(); pose_cases(); ref_helper_cases()

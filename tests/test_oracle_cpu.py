@@ -300,6 +300,17 @@ def test_pose_tail_against_reference_helpers(oracle_mod):
         assert np.allclose(hom_inv(T) @ T, np.eye(4), atol=1e-12)
 
 
+def test_triangulation_against_reference_linear_triangulation(oracle_mod):
+    """The reference's own numpy DLT (`src/utils/linear_triangulation.py`, run in the build container by
+    make_golden.py) and the restatement of cv.triangulatePoints solve the same homogeneous system on
+    noise-free data (exact f64 projections): the dehomogenised points agree to 1e-9 relative."""
+    g = load("ref_helpers.npz")
+    X = oracle_mod.triangulate_points(g["tri_M1"], g["tri_M2"], g["tri_p1"].T, g["tri_p2"].T)
+    P = X / X[3]
+    scale = np.linalg.norm(g["tri_P"][:3], axis=0)
+    assert (np.linalg.norm(P[:3] - g["tri_P"][:3], axis=0) / scale).max() < 1e-9
+
+
 def test_oracle_lmeds_small_point_sets(oracle_mod):
     """8..14 points go through the LMedS restatement: on noise-free data the winner has a vanishing
     median, (nearly) every point is an inlier of the sigma floor (0.001 px: f32-rounded coordinates through a

@@ -16,6 +16,18 @@ def _d(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
+def test_triangulate_against_reference_linear_triangulation(dev):
+    """tests/golden/ref_helpers.npz holds the output of the reference's own numpy DLT triangulation
+    (src/utils/linear_triangulation.py) on exact projections of a noise-free scene; the device
+    triangulation (through the cv2-shaped entry point the reference calls) must land on the same points."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_helpers.npz"))
+    X = cv2_shim.triangulatePoints(g["tri_M1"], g["tri_M2"], g["tri_p1"].T, g["tri_p2"].T)
+    P = X / X[3]
+    scale = np.linalg.norm(g["tri_P"][:3], axis=0)
+    assert (np.linalg.norm(P[:3] - g["tri_P"][:3], axis=0) / scale).max() < 1e-9
+
+
 @pytest.mark.parametrize("n,seed", [(1, 0), (63, 1), (257, 2), (5000, 3)])
 def test_triangulate_equals_oracle(det_math, dev, n, seed):
     """bit for bit against the oracle in its det-math mode (hypot evaluated as sqrt(a*a+b*b), as the
