@@ -79,3 +79,46 @@ def test_fund_4096_hypotheses_8192_points(det_math, dev):
     oF, omask, oinfo = det_math.find_fundamental_mat(sc["p1"], sc["p2"], 0.1, 0.9999, 4096)
     assert (info.best_iter, info.best_model, info.max_good, info.niters) == tuple(int(v) for v in oinfo)
     assert np.array_equal(mask, omask) and np.array_equal(F, oF)
+
+
+def test_pair_pipeline_cfg5_size(det_math, dev):
+    """cfg 5 through the fused batch: 32768 x 32768 descriptors per pair, 4096 F iterations and 65 536 PnP
+    iterations (the oracle's sequential PnP loop stops early, the device replay must stop at the same
+    iteration), two pairs, every decision against the oracle chain."""
+    from visual_odometry_amd import pipeline
+    o = det_math
+    nq = nt = 32768
+    Hf, Hp = 4096, 65536
+    K = synth.K_MALAGA
+
+    def pair(seed):
+        rng = np.random.default_rng(seed)
+        sc = synth.two_view_scene(nq, K=K, size=synth.IMAGE_SIZE["malaga"], seed=seed, outlier_frac=0.0)
+        q, t = synth.sift_like(nq, rng), synth.sift_like(nt, rng)
+        nmatch = int(0.6 * nq)
+        src, dst = rng.permutation(nq)[:nmatch], rng.permutation(nt)[:nmatch]
+        t[dst] = np.clip(np.rint(q[src] + rng.normal(0, 8.0, (nmatch, 128))), 0, 255)
+        kt = rng.uniform(0, 700, (nt, 2)).astype(np.float32)
+        kt[dst] = sc["p2"][src]
+        return q, t, sc["p1"].astype(np.float32), kt, sc["X"].astype(np.float32)
+
+    pairs = [pair(9000 + b) for b in range(2)]
+    st = lambda k: _d(np.stack([p[k] for p in pairs]), dev)
+    r = pipeline.match_and_ransac(st(0), st(1), st(2), st(3), 0.8, 0.5, 0.999, Hf, xyz_q=st(4), K=K, p_threshold=1.0,
+                                  p_confidence=0.9999, p_iters=Hp, first_block_pnp=64)
+    n = r.n_match.cpu().numpy()
+    for b, (q, t, kq, kt, xyz) in enumerate(pairs):
+        oi, od = o.knn2(q, t, mt=True)                  # the multi-threaded oracle matcher (same arithmetic)
+        keep = o.ratio_test(od, 0.8)
+        oq, ot = np.nonzero(keep)[0].astype(np.int32), oi[keep, 0].astype(np.int32)
+        assert n[b] == len(oq) and n[b] > 10000
+        assert np.array_equal(r.match_q[b, :n[b]].cpu().numpy(), oq) and np.array_equal(r.match_t[b, :n[b]].cpu().numpy(), ot)
+        p1, p2 = kq[oq], kt[ot]
+        F, mask, info = o.find_fundamental_mat(p1, p2, 0.5, 0.999, Hf)
+        assert tuple(r.f_result[b].cpu().numpy()) == tuple(int(v) for v in info)
+        assert np.array_equal(r.F[b].cpu().numpy().reshape(3, 3), F)
+        assert np.array_equal(r.f_mask[b, :n[b]].cpu().numpy(), mask.ravel())
+        ok, rvec, tvec, inl, pinfo = o.solve_pnp_ransac(xyz[oq], p2, K, Hp, 1.0, 0.9999)
+        assert tuple(r.p_result[b].cpu().numpy()) == tuple(int(v) for v in pinfo)
+        assert int(pinfo[3]) < Hp                       # the sequential loop stopped early
+        assert np.array_equal(np.nonzero(r.p_mask[b, :n[b]].cpu().numpy())[0], inl.ravel())
