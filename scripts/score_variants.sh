@@ -3,7 +3,7 @@
 # kernel time differs.   bash scripts/score_variants.sh build   |   bash scripts/score_variants.sh run
 set -e
 cd "$(dirname "$0")/.."
-VARS="1_1 2_1 4_1 8_1 16_1 4_2"
+VARS="${VARS:-4_1 4_6 4_7 4_8}"
 if [ "$1" = build ]; then
   mkdir -p ablate/vobj
   for f in vo_runtime vo_knn vo_ransac vo_solvers vo_epnp vo_epnp_dev vo_pipeline vo_pose; do
@@ -16,7 +16,7 @@ if [ "$1" = build ]; then
   done
 else
   for v in $VARS; do
-    VO_HIP_LIB=$PWD/ablate/libvo_score_$v.so timeout -k 10 200 python -u bench.py --steps 6 --warmup 2 --no-cpu --pairs 64 > gpurun_out/sv$v.log 2>&1 || { tail -5 gpurun_out/sv$v.log; exit 1; }
+    VO_HIP_LIB=$PWD/ablate/libvo_score_$v.so timeout -k 10 200 python -u bench.py --steps 20 --warmup 3 --no-cpu --pairs 256 > gpurun_out/sv$v.log 2>&1 || { tail -5 gpurun_out/sv$v.log; exit 1; }
     python -c "
 import json;l=json.loads(open('gpurun_out/sv$v.log').read().strip().splitlines()[-1]);print('G_MINW $v score_fund us', round(l['kernel_avg_us']['score_fund'],1), 'ms/step', round(l['ms_per_step'],2))"
   done
