@@ -154,3 +154,35 @@ def test_deferred_pnp_wait_gives_the_same_results(dev):
     for r, want in zip(outs, ref):
         for k, v in want.items():
             assert np.array_equal(getattr(r, k).cpu().numpy(), v), k
+
+
+def test_finish_small_pairs_runs_lmeds(det_math, dev):
+    """Pairs with 8..14 matches: the fused batch leaves them without an F model, finish_small_pairs gives them
+    what cv2.findFundamentalMat's LMedS branch gives (the oracle's restatement of it), other pairs untouched."""
+    o = det_math
+    nq, nt = 12, 60
+    rng = np.random.default_rng(5)
+    pairs = []
+    for b in range(3):
+        sc = synth.two_view_scene(nq, K=synth.K_MALAGA, size=synth.IMAGE_SIZE["malaga"], seed=4000 + b, outlier_frac=0.0)
+        q, t = synth.sift_like(nq, rng), synth.sift_like(nt, rng)
+        k = nq if b < 2 else 5                                   # pair 2: only 5 matches -> nothing to do
+        dst = rng.permutation(nt)[:k]
+        t[dst] = np.clip(np.rint(q[:k] + rng.normal(0, 4.0, (k, 128))), 0, 255)
+        kt = rng.uniform(0, 700, (nt, 2)).astype(np.float32)
+        kt[dst] = sc["p2"][:k]
+        pairs.append((q, t, sc["p1"].astype(np.float32), kt))
+    st = lambda k: _d(np.stack([p[k] for p in pairs]), dev)
+    r = pipeline.match_and_ransac(st(0), st(1), st(2), st(3), 0.8, 1.0, 0.99, 200)
+    n = r.n_match.cpu().numpy()
+    assert 8 <= n[0] <= 14 and 8 <= n[1] <= 14 and n[2] < 8
+    assert not r.f_mask.any() and (r.f_result[:, 2] == 0).all()   # the fused batch: no model for any of them
+    assert pipeline.finish_small_pairs(r, 1.0, 0.99, 200) == 2
+    for b in range(2):
+        p = r.pts4[b, :n[b]].cpu().numpy()
+        oF, omask, oinfo = o.find_fundamental_mat(p[:, :2], p[:, 2:], 1.0, 0.99, 200)
+        assert oF is not None
+        assert np.array_equal(r.F[b].cpu().numpy().reshape(3, 3), oF)
+        assert np.array_equal(r.f_mask[b, :n[b]].cpu().numpy(), omask.ravel()) and not r.f_mask[b, n[b]:].any()
+        assert tuple(r.f_result[b].cpu().numpy()) == tuple(int(v) for v in oinfo)
+    assert not r.f_mask[2].any() and int(r.f_result[2, 2]) == 0

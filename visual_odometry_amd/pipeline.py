@@ -148,6 +148,30 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
     return out
 
 
+def finish_small_pairs(res: PairBatchResult, f_threshold: float, f_confidence: float, f_iters: int) -> int:
+    """Pairs with 8..14 matches: cv2.findFundamentalMat runs its LMedS registrator there, which
+    the fused batch does not (it leaves them without a model).  This reads `n_match` back (one host
+    synchronisation), runs the single-pair entry point -- device 7-point solver and median ranking -- for
+    those pairs only and writes F, mask and result into `res`.  Returns how many pairs it handled.  Pairs
+    with exactly 7 matches keep "no model": OpenCV returns every 7-point solution stacked there, which a
+    (B,9) model array cannot hold."""
+    from . import ransac
+    n = res.n_match.cpu().numpy()
+    small = [int(b) for b in range(len(n)) if 8 <= n[b] <= 14]
+    for b in small:
+        p = res.pts4[b, :n[b]].cpu().numpy()
+        F, mask, info = ransac.find_fundamental_ransac(p[:, :2], p[:, 2:], f_threshold, f_confidence, f_iters)
+        res.f_mask[b].zero_()
+        res.F[b].zero_()
+        if mask is not None:
+            res.f_mask[b, :n[b]] = torch.from_numpy(mask.ravel().astype("uint8")).to(res.f_mask.device)
+        if F is not None:
+            res.F[b] = torch.from_numpy(F.reshape(9)).to(res.F.device)
+        row = [info.best_iter, info.best_model, info.max_good if F is not None else 0, info.niters]
+        res.f_result[b] = torch.tensor(row, dtype=torch.int32, device=res.f_result.device)
+    return len(small)
+
+
 def pose_tail(res: PairBatchResult, K, max_depth: Optional[float] = None):
     """The 2D-2D pose tail of src/twoDtwoD.py:57-79 for every pair of `res`, on the device:
     E = K^T F K -> decomposeEssentialMatrix -> disambiguateRelativePose over the F inliers.
