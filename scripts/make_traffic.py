@@ -18,7 +18,7 @@ for k, d in out.items():
     d["hbm_bytes_per_launch"] = int(2 * d["FETCH_SIZE_KB_per_launch"] * 1024 + d["WRITE_SIZE_KB_per_launch"] * 1024)
 out["_pairs"] = pairs
 out["_how"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of `python3 bench.py --steps 2 --warmup 1 "
-               f"--no-cpu` ({pairs} frame pairs per launch), averaged over launches; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at "
+               f"--no-cpu --no-latency` ({pairs} frame pairs per launch), averaged over launches; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at "
                "64 B); KB as reported by rocprofv3")
 json.dump(out, open("profiles/r1_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

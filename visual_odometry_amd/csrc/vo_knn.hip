@@ -43,6 +43,9 @@
 #ifndef VO_SCHED
 #define VO_SCHED 0
 #endif
+#ifndef VO_KNN_XCD
+#define VO_KNN_XCD 1         /* problems of a batch are pinned to XCDs (shared L2 for the train rows of a problem) */
+#endif
 #ifndef VO_ABLATE
 #define VO_ABLATE 0      /* 1, 2: timing experiments only (scripts/knn_ablate.sh), results are wrong */
 #endif
@@ -140,7 +143,21 @@ void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict_
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // the ONLY LDS object (2 buffers)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qblock = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+    // Workgroups are dealt to the 8 XCDs round robin in launch order (x fastest).  All workgroups of one
+    // problem stream the same train rows, so they should share an L2: with the batch a multiple of 8, the
+    // workgroups an XCD receives are re-labelled to walk through whole problems one after the other.
+    int qblock = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+#if VO_KNN_XCD
+    if ((gridDim.z & 7) == 0) {
+        const int per = gridDim.x * gridDim.y;
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int xcd = lin & 7, slot = lin >> 3;
+        const int inner = slot % per;
+        b = (slot / per) * 8 + xcd;
+        qblock = inner % gridDim.x;
+        split = inner / gridDim.x;
+    }
+#endif
     q += (size_t)b * nq * kDim;
     t += (size_t)b * nt * kDim;
     tnorm += (size_t)b * nt;
