@@ -49,6 +49,21 @@ def test_knn2_batched_equals_single(oracle_mod, dev):
         assert np.array_equal(np.sqrt(d2[b].cpu().numpy().astype(np.float32)), od)
 
 
+@pytest.mark.parametrize("B,nq,nt", [(8, 600, 2100), (16, 1100, 900), (24, 300, 300)])
+def test_knn2_batch_multiple_of_8_distinct_problems(oracle_mod, dev, B, nq, nt):
+    """batches that are a multiple of 8 take the XCD-aware re-labelling of the workgroups (every problem
+    pinned to one XCD): distinct problems, several query blocks and train splits, each against the oracle."""
+    qs, ts = zip(*[synth.sift_like_pair(nq, nt, 300 + 17 * b + B) for b in range(B)])
+    q = torch.from_numpy(np.stack(qs)).to(dev); t = torch.from_numpy(np.stack(ts)).to(dev)
+    qi8, qn, _ = ops.desc_to_i8(q.reshape(-1, 128)); ti8, tn, _ = ops.desc_to_i8(t.reshape(-1, 128))
+    idx, d2 = ops.knn2(qi8.reshape(B, nq, 128), qn.reshape(B, nq), ti8.reshape(B, nt, 128), tn.reshape(B, nt))
+    idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+    for b in range(B):
+        oi, od = oracle_mod.knn2(qs[b], ts[b], mt=True)
+        assert np.array_equal(idx[b], oi), b
+        assert np.array_equal(np.sqrt(d2[b].astype(np.float32)), od), b
+
+
 def test_knn2_single_split_path(oracle_mod, dev):
     """batch large enough that one train split per workgroup is used (no merge kernel)."""
     B, nq, nt = 40, 600, 300
