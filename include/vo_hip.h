@@ -166,6 +166,25 @@ int vo_ransac_batch(int kind, const int32_t* samples, int H, const void* pts, co
                     double* best_model, double* best_rvec, uint8_t* mask, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* vo_ransac_batch for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments,
+ * results and kernels as vo_ransac_batch, minus the workspace: the scratch memory (model slots,
+ * compacted model lists, count tables) is a fixed array of VO_RANSAC_STATIC_MAX_BYTES inside the
+ * library's code object, one copy per GPU, held until the process ends.  The call itself performs no
+ * hipMalloc / hipFree or any other allocating call; inputs and outputs are still the caller's.
+ *   - problems whose vo_ransac_workspace_bytes(kind, H, batch) exceeds vo_ransac_static_max_bytes()
+ *     are rejected with VO_ESIZE (what fits, as H x batch: kind 0 up to 262144, e.g. 4096 iterations x 64
+ *     pairs; kind 1 up to 65536; kind 2 up to 262144 -- ask vo_ransac_workspace_bytes for other shapes);
+ *   - all calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
+ *     threads) race; serialise them or use vo_ransac_batch with separate workspaces;
+ *   - the array keeps the previous call's contents; the call clears what must start at zero. */
+#define VO_RANSAC_STATIC_MAX_BYTES (64u << 20)
+size_t vo_ransac_static_max_bytes(void);
+int vo_ransac_batch_static(int kind, const int32_t* samples, int H, const void* pts, const float* img,
+                           const double* K4_host, int N, const int32_t* n_dev, int batch, float thr2,
+                           double confidence, int max_iters, int first_block, int32_t* result,
+                           double* best_model, double* best_rvec, uint8_t* mask, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Keeping a frame pair on the device between matching and RANSAC.
  * ---------------------------------------------------------------------------------- */

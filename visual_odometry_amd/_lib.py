@@ -56,6 +56,9 @@ _SIGNATURES = {
     "vo_ransac_workspace_bytes": (_sz, [_i, _i, _i]),
     "vo_ransac_batch": (_i, [_i, _vp, _i, _vp, _vp, C.POINTER(_d), _i, _vp, _i, _f, _d, _i, _i, _vp, _vp, _vp, _vp,
                              _vp, _sz, _vp]),
+    "vo_ransac_static_max_bytes": (_sz, []),
+    "vo_ransac_batch_static": (_i, [_i, _vp, _i, _vp, _vp, C.POINTER(_d), _i, _vp, _i, _f, _d, _i, _i, _vp, _vp, _vp, _vp,
+                                    _vp]),
     "vo_host_gen_subsets": (_i, [_i, _i, _i, _vp, _vp]),
     "vo_host_update_num_iters": (_i, [_d, _d, _i, _i]),
     "vo_host_epnp": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),

@@ -9,6 +9,7 @@
 #include "vo_common.h"
 #include <float.h>
 #include <math.h>
+#include <mutex>
 
 namespace {
 
@@ -292,6 +293,59 @@ extern "C" int vo_ransac_batch(int kind, const int32_t* samples, int H, const vo
     }
     return vo_launch_mask_best(kind, w.models, H * width, width, aux_w ? w.aux : nullptr, aux_w, best_rvec, result, pts, img,
                                n_dev, N, batch, K4_host, thr2, mask, best_model, s);
+}
+
+// ---- the allocation-free variant's workspace: one fixed array per GPU, in the code object -------
+// `scratch` is a host-side stand-in here, not a device address: host code only ever hands it to
+// hipGetSymbolAddress (once per device, with that device current) and uses the pointer that comes back.
+#define VO_RANSAC_STATIC_BYTES ((size_t)VO_RANSAC_STATIC_MAX_BYTES)
+static __device__ __align__(256) unsigned char scratch[VO_RANSAC_STATIC_MAX_BYTES];
+
+namespace {
+enum { kMaxDevices = 64 };
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices];            // device address of `scratch` on device d, or null
+
+// address of the current device's copy of `scratch`; resolved on the first call per device
+int scratch_of_current_device(void** out)
+{
+    int d = -1;
+    VO_HIP_TRY(hipGetDevice(&d));
+    VO_CHECK_ARG(d >= 0 && d < kMaxDevices, VO_ESIZE, "vo_ransac_batch_static: device ordinal %d not supported", d);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[d]) {
+        void* p = nullptr;
+        VO_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        VO_CHECK_ARG(p && ((uintptr_t)p & 255) == 0, VO_EHIP, "vo_ransac_batch_static: bad symbol address %p", p);
+        g_scratch_ptr[d] = p;
+    }
+    *out = g_scratch_ptr[d];
+    return VO_OK;
+}
+}  // namespace
+
+extern "C" size_t vo_ransac_static_max_bytes(void) { return VO_RANSAC_STATIC_BYTES; }
+
+extern "C" int vo_ransac_batch_static(int kind, const int32_t* samples, int H, const void* pts, const float* img,
+                                      const double* K4_host, int N, const int32_t* n_dev, int batch, float thr2,
+                                      double confidence, int max_iters, int first_block, int32_t* result,
+                                      double* best_model, double* best_rvec, uint8_t* mask, void* stream)
+{
+    VO_CHECK_ARG(kind >= 0 && kind <= 2, VO_EINVAL, "vo_ransac_batch_static: kind must be 0 (F), 1 (E) or 2 (PnP)");
+    VO_CHECK_ARG(H >= 0 && batch >= 0, VO_EINVAL, "vo_ransac_batch_static: negative size");
+    if (batch == 0) return VO_OK;
+    VO_CHECK_ARG((long)H * batch <= 2147483647L / 16, VO_ESIZE, "vo_ransac_batch_static: H x batch too large");
+    const size_t need = H > 0 ? carve(nullptr, kWidth[kind], kMw[kind], kAux[kind], H, batch).bytes : 0;
+    VO_CHECK_ARG(need <= VO_RANSAC_STATIC_BYTES, VO_ESIZE,
+                 "vo_ransac_batch_static: kind %d with H = %d, batch = %d needs %zu bytes of scratch, the built-in array "
+                 "holds %zu; use vo_ransac_batch with a caller-provided workspace", kind, H, batch, need,
+                 VO_RANSAC_STATIC_BYTES);
+    void* ws = nullptr;
+    const int rc = scratch_of_current_device(&ws);
+    if (rc != VO_OK) return rc;
+    // the array keeps the previous call's contents; vo_ransac_batch clears what must start at zero
+    return vo_ransac_batch(kind, samples, H, pts, img, K4_host, N, n_dev, batch, thr2, confidence, max_iters, first_block,
+                           result, best_model, best_rvec, mask, ws, VO_RANSAC_STATIC_BYTES, stream);
 }
 
 extern "C" int vo_ransac_replay(const int32_t* counts, const int32_t* nmodels, int n_iters, int max_models,

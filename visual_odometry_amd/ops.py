@@ -256,8 +256,10 @@ _SAMPLE_WIDTH = {KIND_FUND: 7, KIND_ESS: 5, KIND_PNP: 4}
 
 def ransac_batch(kind: int, samples: torch.Tensor, pts: torch.Tensor, threshold: float, confidence: float,
                  max_iters: int, img: Optional[torch.Tensor] = None, K=None, n_dev: Optional[torch.Tensor] = None,
-                 workspace: Optional[torch.Tensor] = None, first_block: int = 0):
+                 workspace: Optional[torch.Tensor] = None, first_block: int = 0, static_scratch: bool = False):
     """Fused solve -> score -> replay -> mask for a batch of same-shape problems, no host sync.
+    static_scratch=True goes through vo_ransac_batch_static: the library's built-in per-GPU scratch array
+    instead of a workspace tensor (sizes beyond it raise; concurrent calls on one GPU race).
 
     samples (B,H,m) i32; pts (B,N,4) f32 [F] | (B,N,4) f64 [E] | (B,N,3) f32 object points [PnP, with
     img (B,N,2) f32 and K].  first_block > 0: iterations are evaluated in growing blocks and problems
@@ -289,6 +291,11 @@ def ransac_batch(kind: int, samples: torch.Tensor, pts: torch.Tensor, threshold:
     best = torch.empty((B, mw), dtype=torch.float64, device=dev)
     rvec = torch.empty((B, 3), dtype=torch.float64, device=dev) if kind == KIND_PNP else None
     mask = torch.empty((B, N), dtype=torch.uint8, device=dev)
+    if static_scratch:
+        _lib.check(lib.vo_ransac_batch_static(kind, _ptr(samples), H, _ptr(pts), img_p, k4, N, _ptr(nd), B, thr2_of(threshold),
+                                              float(confidence), int(max_iters), int(first_block), _ptr(result), _ptr(best),
+                                              _ptr(rvec), _ptr(mask), _stream()), "vo_ransac_batch_static")
+        return result, best, rvec, mask
     need = lib.vo_ransac_workspace_bytes(kind, H, B)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty((need,), dtype=torch.uint8, device=dev)
