@@ -1,21 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the hot path on MI355X, frame pairs end to end on the device.
 
-Workload (BASELINE.json configs[3], "cfg4"): per frame pair, 8192 x 8192 SIFT-like descriptors are
-matched (f32 -> int8 conversion, exact 2-NN on int8 MFMA, ratio test 0.8), the surviving matches
-are compacted into correspondences (about 4.7k per pair), and two 4096-iteration RANSAC runs are
-evaluated over them: 7-point fundamental matrix (threshold 0.1 px, confidence 0.9999: the
-reference's F parameters; up to 3 models per sample, symmetric epipolar error) and P3P PnP
-(1 px, 0.9999: the reference's Malaga parameters; reprojection error).  Each RANSAC run = sample
-stream of cv::RNG/getSubset generated on the device for the pair's match count -> minimal solves ->
-scoring of every model against every correspondence -> replay of OpenCV's sequential best-model
-bookkeeping incl. its adaptive iteration count -> inlier mask of the winner.  The PnP run evaluates
-its iterations in blocks (256, then 4x more) and stops where OpenCV's loop would have stopped.
-One "step" = one pass over `--pairs` frame pairs per GPU with no host synchronisation inside.
-Inputs are synthetic, seeded, and resident in HBM before the timed region.
+Workloads (`--config`):
+  cfg4 (default; BASELINE.json configs[3]): per frame pair, 8192 x 8192 SIFT-like descriptors are matched
+       (f32 -> int8 conversion, exact 2-NN on int8 MFMA, ratio test 0.8), the surviving matches are compacted
+       into correspondences (about 4.9k per pair), and two 4096-iteration RANSAC runs are evaluated over them:
+       7-point fundamental matrix (threshold 0.1 px, confidence 0.9999: the reference's F parameters; up to 3
+       models per sample, symmetric epipolar error) and P3P PnP (1 px, 0.9999: the reference's Malaga
+       parameters; reprojection error) + the EPnP refit of its inliers.
+  cfg5 (BASELINE.json configs[4], one GPU's share): 32768 x 32768 descriptors per pair, 65 536-iteration P3P
+       PnP-RANSAC over the matches with 55 % of the landmarks replaced by unrelated points (so OpenCV's
+       adaptive loop runs for hundreds of iterations instead of a handful), plus the 4096-iteration F-RANSAC.
+Each RANSAC run = sample stream of cv::RNG/getSubset generated on the device for the pair's match count ->
+minimal solves -> scoring of every model against every correspondence -> replay of OpenCV's sequential
+best-model bookkeeping incl. its adaptive iteration count -> inlier mask of the winner.  One "step" = one
+pass over `--pairs` frame pairs with no host synchronisation inside.  Inputs are synthetic, seeded, and
+resident in HBM before the timed region.
 
-Multi-GPU: frame pairs are independent, so every rank processes its own `--pairs` pairs and there
-is no collective on the data path (weak scaling); value = pairs of all ranks / max-over-ranks time.
+Multi-GPU (`--gpus N`, one process per GPU, torch.distributed backend nccl = RCCL):
+  --mode weak  (default): frame pairs are independent, every rank processes its own `--pairs` pairs, no
+               collective on the data path; value = pairs of all ranks / max-over-ranks time.
+  --mode shard (BASELINE cfg4 "sharded over 2/4/8 GPUs"): ONE batch of `--pairs` pairs is spread over the
+               ranks -- query rows split for the match (one all_gather of the 2-NN rows), the iteration
+               range of every F-RANSAC problem split over the ranks (one all_gather of the count tables and one
+               all-reduce of the winners, replicated replay), whole PnP problems dealt to the ranks (one
+               all_gather of the packed results); strong scaling.
+
+Launch: under torchrun (RANK/LOCAL_RANK/WORLD_SIZE in the environment) this process IS a rank.  Run plainly
+(`python bench.py --gpus N`) it is a launcher: it touches no GPU, starts N fresh rank processes of itself
+and relays rank 0's line.  `--inproc` runs the single rank in this very process (profilers want the program
+itself after `--`).  Every form initialises a real RCCL process group, also with one rank.
 
 Prints ONE JSON line (rank 0).
 """
@@ -24,65 +38,105 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from visual_odometry_amd import _lib, ops, pipeline, synth  # noqa: E402
-
-NQ = NT = 8192
-H = 4096                      # RANSAC iterations (sample sets) per problem
 RATIO = 0.8                   # reference src/params.py:10
 F_THR, F_CONF = 0.1, 0.9999   # reference src/params.py:24-27
 P_THR, P_CONF = 1.0, 0.9999   # reference src/params.py:72-75
 FIRST_BLOCK = 64              # PnP iterations evaluated before the first early-termination check (then x5 per block)
-K = synth.K_MALAGA
-SIZE = synth.IMAGE_SIZE["malaga"]
+
+CONFIGS = {
+    "cfg4": dict(nq=8192, nt=8192, f_iters=4096, p_iters=4096, pairs=256, landmark_outliers=0.0),
+    "cfg5": dict(nq=32768, nt=32768, f_iters=4096, p_iters=65536, pairs=32, landmark_outliers=0.55),
+}
 
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s HBM3E
 I8_OPS_PER_CLK_CU = 8192      # 4 SIMD x 2048 int8 ops/clk (v_mfma_i32_32x32x32_i8: 65536 ops / 32 clk)
-FP64_PEAK_TFLOPS = 78.6       # 256 CU x 128 flop/clk x 2.4 GHz
+VALU_LANES_PER_CLK_CU = 128   # 4 SIMD-32: a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md)
+FP64_FLOP_PER_CLK_CU = 128    # 78.6 TFLOP/s f64 vector at 256 CU x 2.4 GHz
+CLOCK_GHZ = 2.4               # nominal peak clock; the chip holds less under load (profiles/r2_counters.json)
 
 
+# ----------------------------------------------------------------------------------------- launcher
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher(args, argv) -> int:
+    """Start args.gpus rank processes of this script (fresh interpreters: this process never touches the
+    GPU, so nothing GPU-initialised is forked or exec'd) and wait for them."""
+    import torch
+    n = args.gpus
+    have = torch.cuda.device_count()            # does not initialise the GPU
+    if n < 1 or n > max(have, 1):
+        print(f"bench.py: --gpus {n} but {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ----------------------------------------------------------------------------------------- worker
 class PairSet:
     """Device-resident inputs of `pairs` frame pairs (a few distinct seeds, tiled)."""
 
-    def __init__(self, pairs: int, dev: torch.device, rank: int, distinct: int = 4):
+    def __init__(self, cfg, pairs: int, dev, seed_base: int, distinct: int = 4):
+        import numpy as np
+        import torch
+        from visual_odometry_amd import pipeline, synth
         distinct = min(distinct, pairs)
-        made = [synth.frame_pair(NQ, NT, seed=1234 + 1000 * rank + d, K=K, size=SIZE) for d in range(distinct)]
+        K, size = synth.K_MALAGA, synth.IMAGE_SIZE["malaga"]
+        made = [synth.frame_pair(cfg["nq"], cfg["nt"], seed=1234 + seed_base + d, K=K, size=size,
+                                 landmark_outlier_frac=cfg["landmark_outliers"]) for d in range(distinct)]
         sel = [i % distinct for i in range(pairs)]
         up = lambda key: torch.from_numpy(np.stack([made[i][key] for i in sel])).to(dev)
-        self.pairs = pairs
+        self.pairs, self.K = pairs, K
         self.q, self.t = up("q"), up("t")                       # (B, N, 128) f32
         self.kp_q, self.kp_t, self.xyz_q = up("kp_q"), up("kp_t"), up("xyz_q")
-        nbytes = pipeline.workspace_bytes(NQ, NT, pairs, H, H)
+        nbytes = pipeline.workspace_bytes(cfg["nq"], cfg["nt"], pairs, cfg["f_iters"], cfg["p_iters"])
         self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
 
 
-def step(ps: PairSet):
-    """One pass over all pairs; everything is enqueued (main stream + the pipeline's PnP side stream),
-    nothing is read back.  The PnP tail of one step may still be running when the next step starts; the
-    timed region ends with a device-wide synchronize."""
-    return pipeline.match_and_ransac(ps.q, ps.t, ps.kp_q, ps.kp_t, RATIO, F_THR, F_CONF, H, xyz_q=ps.xyz_q, K=K,
-                                     p_threshold=P_THR, p_confidence=P_CONF, p_iters=H, first_block_pnp=FIRST_BLOCK,
-                                     workspace=ps.ws, wait_pnp=False)
+def step(ps: PairSet, cfg, group):
+    """One pass over all pairs; everything is enqueued, nothing is read back.  Weak mode: main stream + the
+    pipeline's PnP side stream (the PnP tail of one step may still be running when the next step starts; the
+    timed region ends with a device-wide synchronize).  Shard mode: one stream, collectives inside."""
+    from visual_odometry_amd import pipeline
+    return pipeline.match_and_ransac(ps.q, ps.t, ps.kp_q, ps.kp_t, RATIO, F_THR, F_CONF, cfg["f_iters"], xyz_q=ps.xyz_q,
+                                     K=ps.K, p_threshold=P_THR, p_confidence=P_CONF, p_iters=cfg["p_iters"],
+                                     first_block_pnp=FIRST_BLOCK, workspace=ps.ws, wait_pnp=False, group=group)
 
 
-def drop_in_latency():
+def drop_in_latency(cfg):
     """Wall clock of the reference-shaped single-pair entry points (host numpy in, host numpy out:
     H2D of the inputs, kernels, stream sync, D2H of the results) on one cfg4-sized frame pair --
     SURVEY.md 8d asks for this beside the device-resident rate; it is not part of `value`."""
-    import contextlib, io
-    from visual_odometry_amd import cv2_shim
+    import contextlib
+    import io
+    import numpy as np
+    import torch
+    from visual_odometry_amd import cv2_shim, synth
     from visual_odometry_amd.features import match_features_indices
-    fp = synth.frame_pair(NQ, NT, seed=77, K=K, size=SIZE)
+    K, size = synth.K_MALAGA, synth.IMAGE_SIZE["malaga"]
+    fp = synth.frame_pair(cfg["nq"], cfg["nt"], seed=77, K=K, size=size)
     out = {}
+
     def timed(name, fn, reps=3):
         fn()                                                  # warm-up (allocations, first-touch)
         ts = []
@@ -93,39 +147,44 @@ def drop_in_latency():
             ts.append((time.perf_counter() - t0) * 1e3)
         out[name + "_ms"] = float(np.median(ts))
         return r
+    H = cfg["f_iters"]
     with contextlib.redirect_stdout(io.StringIO()):
-        qi, ti = timed("match_features_8192x8192", lambda: match_features_indices(fp["q"], fp["t"], RATIO))
+        qi, ti = timed(f"match_features_{cfg['nq']}x{cfg['nt']}", lambda: match_features_indices(fp["q"], fp["t"], RATIO))
         p1, p2 = fp["kp_q"][qi], fp["kp_t"][ti]
-        timed("findFundamentalMat_4096_iters", lambda: cv2_shim.findFundamentalMat(p1, p2, cv2_shim.RANSAC, F_THR, F_CONF, H))
-        timed("solvePnPRansac_4096_iters", lambda: cv2_shim.solvePnPRansac(fp["xyz_q"][qi], p2, K, None, iterationsCount=H,
-                                                                         reprojectionError=P_THR, confidence=P_CONF,
-                                                                         flags=cv2_shim.SOLVEPNP_P3P))
+        timed(f"findFundamentalMat_{H}_iters", lambda: cv2_shim.findFundamentalMat(p1, p2, cv2_shim.RANSAC, F_THR, F_CONF, H))
+        timed(f"solvePnPRansac_{cfg['p_iters']}_iters",
+              lambda: cv2_shim.solvePnPRansac(fp["xyz_q"][qi], p2, K, None, iterationsCount=cfg["p_iters"],
+                                              reprojectionError=P_THR, confidence=P_CONF, flags=cv2_shim.SOLVEPNP_P3P))
     out["matches"] = int(len(qi))
     out["note"] = ("median of 3 calls each, one frame pair, host arrays in and out (PCIe both ways, one stream sync per call); "
                    "the batched device-resident pipeline is what `value` measures")
     return out
 
 
-def cpu_baseline(max_seconds: float = 25.0):
+def cpu_baseline(cfg, max_seconds: float = 25.0):
     """The oracle (CPU restatement of the OpenCV routines; OpenCV itself is absent) on the same
     workload, a bounded number of frame pairs."""
+    import numpy as np
     import oracle
+    from visual_odometry_amd import synth
 
     oracle.build()
+    K, size = synth.K_MALAGA, synth.IMAGE_SIZE["malaga"]
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
     os.environ.setdefault("OMP_NUM_THREADS", str(threads))
     dt, done, parts = 0.0, 0, [0.0, 0.0, 0.0]
     while done < 4 and (done == 0 or dt * (done + 1) / done < max_seconds):
-        fp = synth.frame_pair(NQ, NT, seed=1234 + done, K=K, size=SIZE)
+        fp = synth.frame_pair(cfg["nq"], cfg["nt"], seed=1234 + done, K=K, size=size,
+                              landmark_outlier_frac=cfg["landmark_outliers"])
         t0 = time.perf_counter()
         idx, dist = oracle.knn2(fp["q"], fp["t"], mt=True)
         keep = oracle.ratio_test(dist, RATIO)
         qi, ti = np.nonzero(keep)[0], idx[keep, 0]
         p1, p2, xyz = fp["kp_q"][qi], fp["kp_t"][ti], fp["xyz_q"][qi]
         t1 = time.perf_counter()
-        oracle.find_fundamental_mat(p1, p2, F_THR, F_CONF, H)
+        oracle.find_fundamental_mat(p1, p2, F_THR, F_CONF, cfg["f_iters"])
         t2 = time.perf_counter()
-        oracle.solve_pnp_ransac(xyz, p2, K, H, P_THR, P_CONF)
+        oracle.solve_pnp_ransac(xyz, p2, K, cfg["p_iters"], P_THR, P_CONF)
         t3 = time.perf_counter()
         dt += t3 - t0
         parts = [parts[0] + t1 - t0, parts[1] + t2 - t1, parts[2] + t3 - t2]
@@ -137,7 +196,7 @@ def cpu_baseline(max_seconds: float = 25.0):
                       f"OpenCV routines, not OpenCV"}
 
 
-def iteration_blocks(first):
+def iteration_blocks(H, first):
     out, h0, stage = [], 0, 0
     while h0 < H:
         h1 = H
@@ -149,70 +208,77 @@ def iteration_blocks(first):
     return out
 
 
-def models_scored(nm, result, first):
+def models_scored(nm, result, H, first):
     """Models the scoring launches evaluated: samples without a solution have none, and iteration
     blocks that start where OpenCV's loop has already ended are skipped (block k ran iff
     h0_k <= best_iter or h0_k < final niters)."""
     per_pair = []
     for b in range(len(nm)):
         best_iter, niters = int(result[b, 0]), int(result[b, 3])
-        per_pair.append(sum(int(nm[b][h0:h1].sum()) for h0, h1 in iteration_blocks(first)
+        per_pair.append(sum(int(nm[b][h0:h1].sum()) for h0, h1 in iteration_blocks(H, first)
                             if h0 == 0 or h0 <= best_iter or h0 < niters))
     return per_pair
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=256, help="frame pairs per GPU per step")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-latency", action="store_true",
-                    help="skip the single-pair drop_in_latency leg (profiling runs: keeps rocprofv3's per-kernel "
-                         "averages to the launches of the steps)")
-    args = ap.parse_args()
+def _load_json(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+
+def worker(args) -> int:
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from visual_odometry_amd import _lib, ops, parallel
+
+    cfg = dict(CONFIGS[args.config])
+    B = args.pairs or cfg["pairs"]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    world = int(os.environ.setdefault("WORLD_SIZE", "1"))
+    rank = int(os.environ.setdefault("RANK", "0"))
+    local = int(os.environ.setdefault("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.require_device(local)
-    dist = None
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:      # under torchrun, also with one rank
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    dist.init_process_group("nccl", device_id=dev)            # RCCL, also with one rank
+    shard = args.mode == "shard"
+    group = parallel.WORLD if shard else None
 
-    ps = PairSet(args.pairs, dev, rank)
+    # shard mode: every rank holds the SAME batch (seed_base 0); weak mode: every rank its own pairs
+    ps = PairSet(cfg, B, dev, 0 if shard else 1000 * rank)
     lib = _lib.load()
     for _ in range(args.warmup):
-        step(ps)
+        step(ps, cfg, group)
     torch.cuda.synchronize()
     # HIP events around single launches inside the entry points (the scoring kernels of both RANSAC
     # runs and the kNN sweep kernel), recorded on the stream those kernels run on
     cap = 16 * args.steps + 8
     _lib.check(lib.vo_profile_enable((1 << 1) | (1 << 4), cap), "vo_profile_enable")
-    if dist:
-        dist.barrier()
+    dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step(ps)
+        res = step(ps, cfg, group)
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
 
     tags = np.zeros(cap, np.int32); ms = np.zeros(cap, np.float32)
     nrec = lib.vo_profile_collect(tags.ctypes.data, ms.ctypes.data, cap)
     _lib.check(nrec, "vo_profile_collect")
     lib.vo_profile_enable(0, 0)
+    res.check_descriptors()                                   # the batched path only flags bad descriptors: raise here
     # tag 0x1000 = kNN sweep kernel; otherwise kind | iteration-block << 8 of a scoring launch.  The
     # scoring time of one RANSAC run is the sum over its iteration blocks (later blocks return at
     # once for problems that already terminated).
@@ -222,80 +288,116 @@ def main():
         tot[name] += float(ms[i]) * 1e-3
     avg = {k: v / args.steps for k, v in tot.items()}
 
-    # ---- what the launches processed, counted outside the timed region from the last step's outputs
-    B = args.pairs
+    # ---- what this rank's launches processed, counted outside the timed region from the last step's outputs
+    NQ, NT, HF, HP = cfg["nq"], cfg["nt"], cfg["f_iters"], cfg["p_iters"]
     n_match = res.n_match.cpu().numpy().astype(np.int64)
     res_f, res_p = res.f_result.cpu().numpy(), res.p_result.cpu().numpy()
+    # shard mode: this rank scores its slice of every F problem's iterations and whole PnP problems of its pairs
+    h_f = parallel.shard_bounds(HF, rank, world) if shard else (0, HF)
+    p_pairs = range(*parallel.shard_bounds(B, rank, world)) if shard else range(B)
     nm_f, nm_p = [], []
     for b in range(B):
         n = int(n_match[b])
-        nm_f.append(ops.solve_7pt(res.f_samples[b], res.pts4[b, :n])[1].cpu().numpy())
-        nm_p.append(ops.solve_p3p(res.p_samples[b], res.obj[b, :n], res.img[b, :n], K)[2].cpu().numpy())
-    mf, mp = models_scored(nm_f, res_f, 0), models_scored(nm_p, res_p, FIRST_BLOCK)
+        nm_f.append(ops.solve_7pt(res.f_samples[b, h_f[0]:h_f[1]], res.pts4[b, :n])[1].cpu().numpy())
+    for b in p_pairs:
+        n = int(n_match[b])
+        nm_p.append(ops.solve_p3p(res.p_samples[b], res.obj[b, :n], res.img[b, :n], ps.K)[2].cpu().numpy())
+    mf = [int(x.sum()) for x in nm_f] if shard else models_scored(nm_f, res_f, HF, 0)
+    mp = models_scored(nm_p, res_p[list(p_pairs)], HP, FIRST_BLOCK)
     evals_f = int(sum(m * n for m, n in zip(mf, n_match)))
-    evals_p = int(sum(m * n for m, n in zip(mp, n_match)))
+    evals_p = int(sum(m * n for m, n in zip(mp, n_match[list(p_pairs)])))
     n_models_f, n_models_p = int(sum(mf)), int(sum(mp))
+    nq_local = (parallel.shard_bounds(NQ, rank, world)[1] - parallel.shard_bounds(NQ, rank, world)[0]) if shard else NQ
 
     prop = torch.cuda.get_device_properties(dev)
     cus = prop.multi_processor_count
-    clock_ghz = 2.4
-    i8_peak_tops = cus * I8_OPS_PER_CLK_CU * clock_ghz * 1e9 / 1e12
+    i8_peak_tops = cus * I8_OPS_PER_CLK_CU * CLOCK_GHZ * 1e9 / 1e12
+    valu_peak = cus * VALU_LANES_PER_CLK_CU * CLOCK_GHZ * 1e9 / 1e12        # T lane-instructions/s
+    fp64_peak = cus * FP64_FLOP_PER_CLK_CU * CLOCK_GHZ * 1e9 / 1e12
 
-    # algorithmic bytes per (model, correspondence) evaluation = 16 B (x1 y1 x2 y2 f32)
-    # or 20 B (PnP), plus per model its 72 / 96 B read and the 4 B count
-    sf_gbs = (evals_f * 16 + n_models_f * (72 + 4)) / avg["score_fund"] / 1e9
-    sp_gbs = (evals_p * 20 + n_models_p * (96 + 4)) / avg["score_pnp"] / 1e9
-    knn_tops = 2.0 * NQ * NT * 128 * B / avg["knn2"] / 1e12
-
-    # physical HBM traffic per launch: PMC counters need their own rocprofv3 passes, so they are
-    # measured separately on the same command (scripts/gpu_pmc.sh) and kept under profiles/
-    traffic = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as fh:
-            tj = json.load(fh)
-        if args.pairs == tj.get("_pairs", 16):
-            traffic = {k: v["hbm_bytes_per_launch"] for k, v in tj.items() if isinstance(v, dict)}
-    except (OSError, ValueError, KeyError):
-        pass
-    tnote = "HBM bytes per launch from rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes: profiles/r1_traffic.json"
+    # physical HBM traffic, SQ instruction counts and the clock under load come from rocprofv3 --pmc passes of
+    # this same command (scripts/gpu_roofline.sh -> profiles/r2_counters.json); the per-evaluation instruction
+    # count of the F scoring loop from the disassembled code object (scripts/isa_count.py -> profiles/r2_score_fund_isa.json)
+    ctr = _load_json("r2_counters.json") or {}
+    isa = _load_json("r2_score_fund_isa.json") or {}
+    same_shape = ctr.get("_pairs") == B and ctr.get("_config", "cfg4") == args.config and not shard
+    kc = lambda k: (ctr.get(k) or {}) if same_shape else {}
+    valu_per_eval = isa.get("valu_per_evaluation")
+    t_f = max(avg["score_fund"], 1e-12)
+    t_p = max(avg["score_pnp"], 1e-12)
+    t_k = max(avg["knn2"], 1e-12)
+    sf = {"kernel": "score_kernel<F>", "bound": "valu-issue", "unit": "T VALU lane-instructions/s",
+          "peak": valu_peak, "traffic": kc("score_fund_kernel").get("hbm_bytes_per_launch"),
+          "units_per_launch": f"{evals_f} (model, correspondence) evaluations = {n_models_f} models x the pair's "
+                              f"correspondences ({B} frame pairs)"}
+    if valu_per_eval:
+        sf["achieved"] = evals_f * valu_per_eval / t_f / 1e12
+        sf["frac"] = sf["achieved"] / valu_peak
+        sf["valu_instructions_per_evaluation"] = valu_per_eval
+        sf["all_instructions_per_evaluation"] = isa.get("all_per_evaluation")
+        sf["note"] = (f"achieved = evaluations x {valu_per_eval} VALU instructions per evaluation (inner loop of the shipped "
+                      f"code object, profiles/r2_score_fund_isa.json; one lane = one model) / launch time; peak = {cus} CU x "
+                      f"4 SIMD x 32 lanes/clk x {CLOCK_GHZ} GHz (a wave64 VALU instruction issues over 2 cycles).  The kernel "
+                      "keeps 256 models in registers per workgroup and re-reads correspondences from LDS, so it is bound "
+                      "by instruction issue, not by HBM (traffic = measured HBM bytes per launch)")
+        c = kc("score_fund_kernel")
+        if c.get("clock_ghz"):
+            sf["clock_ghz_under_load"] = c["clock_ghz"]
+            sf["frac_at_measured_clock"] = sf["achieved"] / (cus * VALU_LANES_PER_CLK_CU * c["clock_ghz"] * 1e9 / 1e12)
+        if c.get("SQ_INSTS_VALU") and c.get("evaluations_per_launch"):
+            sf["valu_per_evaluation_from_SQ_INSTS_VALU"] = c["SQ_INSTS_VALU"] * 64 / c["evaluations_per_launch"]
+    else:
+        sf["achieved"], sf["frac"] = None, None
+        sf["note"] = "profiles/r2_score_fund_isa.json missing: run scripts/isa_count.py"
+    sf["effective_streaming_GBps"] = (evals_f * 16 + n_models_f * (72 + 4)) / t_f / 1e9
+    sf["effective_streaming_note"] = ("SURVEY.md 8d's figure: 16 B per evaluation as if every model streamed every correspondence "
+                                      f"from HBM; not a roofline for this kernel ({HBM_PEAK_GBS:.0f} GB/s peak is never touched)")
+    sf["f64_tflops_equivalent"] = evals_f * 49 / t_f / 1e12
+    sf["f64_equivalent_note"] = ("49 f64 flops per evaluation of the scalar definition whose verdicts the kernel reproduces bit "
+                                 "for bit; executed as ~28 f32 instructions + rare f64 fallbacks")
+    sp_flops = evals_p * 30 / t_p / 1e12
     roof = {
-        "score_fund": {"kernel": "score_kernel<F>", "bound": "hbm", "achieved": sf_gbs, "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": sf_gbs / HBM_PEAK_GBS, "traffic": traffic.get("score_fund_kernel"),
-                       "traffic_note": tnote,
-                       "note": "effective streaming bytes (16 B per model x correspondence); the tiled kernel "
-                               "re-uses points from LDS so physical HBM traffic is far lower and the real limiter "
-                               "is VALU issue: ~25 f32 ops per evaluation in the filter tier, the f64 filter / exact "
-                               "f64 evaluation only within rounding distance of the threshold (DESIGN.md 7)",
-                       "f64_tflops_equivalent": evals_f * 49 / avg["score_fund"] / 1e12,
-                       "f64_equivalent_note": "49 f64 flops per evaluation of the scalar definition whose verdicts the kernel "
-                                              "reproduces bit for bit; not executed as such (f64 vector peak is 78.6 TFLOP/s)",
-                       "units_per_launch": f"{evals_f} evaluations = {n_models_f} models x the pair's correspondences ({B} frame pairs)"},
-        "score_pnp": {"kernel": "score_kernel<PnP>", "bound": "hbm", "achieved": sp_gbs, "peak": HBM_PEAK_GBS,
-                      "unit": "GB/s", "frac": sp_gbs / HBM_PEAK_GBS, "traffic": None,
-                      "note": "the PnP chain runs on a side stream underneath the F chain's getSubset/solver kernels, "
-                              "so these launches share the GPU and their durations are upper bounds",
+        "score_fund": sf,
+        "score_pnp": {"kernel": "score_kernel<PnP>", "bound": "fp64-valu", "achieved": sp_flops, "peak": fp64_peak,
+                      "unit": "TFLOP/s", "frac": sp_flops / fp64_peak, "traffic": None,
+                      "effective_streaming_GBps": (evals_p * 20 + n_models_p * (96 + 4)) / t_p / 1e9,
+                      "note": "30 f64 flops per evaluation (SURVEY.md 8d: 3x4 projection, one correctly rounded divide, pixel "
+                              "mapping); in weak mode the PnP chain runs on a side stream under the F chain, so these launches "
+                              "share the GPU and their durations are upper bounds; standalone figures: profiles/r2_score_standalone.json",
                       "units_per_launch": f"{evals_p} evaluations = {n_models_p} models x the pair's correspondences "
-                                          f"({B} frame pairs, {len(iteration_blocks(FIRST_BLOCK))} iteration-block launches summed)"},
-        "knn2": {"kernel": "knn2_partial_kernel", "bound": "mfma", "achieved": knn_tops, "peak": i8_peak_tops,
-                 "unit": "TOP/s", "frac": knn_tops / i8_peak_tops, "traffic": traffic.get("knn2_partial_kernel"),
-                 "note": f"int8 dense peak = {cus} CU x {I8_OPS_PER_CLK_CU} ops/clk x {clock_ghz} GHz; the sweep is bound by "
-                         "VALU issue (2.5 integer ops per distance for the exact top-2), see DESIGN.md",
-                 "units_per_launch": f"{B} frame pairs of {NQ} x {NT} descriptors"},
+                                          f"({B} frame pairs, {len(iteration_blocks(HP, FIRST_BLOCK))} iteration-block launches summed)"},
+        "knn2": {"kernel": "knn2_partial_kernel", "bound": "mfma", "achieved": 2.0 * nq_local * NT * 128 * B / t_k / 1e12,
+                 "peak": i8_peak_tops, "unit": "TOP/s", "traffic": kc("knn2_partial_kernel").get("hbm_bytes_per_launch"),
+                 "note": f"int8 dense peak = {cus} CU x {I8_OPS_PER_CLK_CU} ops/clk x {CLOCK_GHZ} GHz; see DESIGN.md 4.1",
+                 "units_per_launch": f"{B} frame pairs of {nq_local} x {NT} descriptors"},
     }
+    roof["knn2"]["frac"] = roof["knn2"]["achieved"] / i8_peak_tops
     dominant = max(tot, key=tot.get)
-    pairs_total = B * world * args.steps
+    pairs_total = B * args.steps * (1 if shard else world)
+    wl = {"cfg4": f"cfg4: {NQ}x{NT}x128 SIFT match + ratio test -> matched correspondences (on device) -> {HF}-iteration "
+                  f"7-point F-RANSAC (thr 0.1 px: every iteration runs) and P3P PnP-RANSAC with maxIters {HP} (+ EPnP refit of "
+                  "its inliers) over them, per frame pair; ~91 % of the PnP correspondences are inliers, so OpenCV's adaptive "
+                  "loop -- which the pipeline reproduces -- ends after 3-12 iterations: the first block of 64 iterations is what gets scored",
+          "cfg5": f"cfg5 (one GPU's share of the sweep): {NQ}x{NT}x128 SIFT match + ratio test -> matched correspondences -> "
+                  f"P3P PnP-RANSAC with maxIters {HP} over them with 55 % of the landmarks replaced by unrelated points "
+                  f"(OpenCV's adaptive loop runs a few hundred iterations; blocks of 64, 320, 1600, ... are scored) + EPnP refit, "
+                  f"and the {HF}-iteration 7-point F-RANSAC, per frame pair"}[args.config]
+    par_note = (f"ONE batch of {B} pairs over {world} GPU(s): query rows split for the match (all_gather of the 2-NN rows), "
+                "F-RANSAC iteration ranges split over the ranks (all_gather of count tables + all-reduce of winners, replicated replay), "
+                "PnP problems dealt to the ranks by pair (all_gather of the packed results)"
+                if shard else f"pairs sharded over {world} GPU(s), no collective on the data path")
     line = {
         "metric": "matched frame-pairs/sec", "value": pairs_total / dt, "unit": "frame-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8 (matching) / f64 (RANSAC; F scoring filtered in f32, verdicts identical)",
+        "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
+        "dtype": "i8 (matching) / f64 (RANSAC; F scoring filtered in f32, verdicts identical)",
         "data": "synthetic",
-        "config": {"workload": "cfg4: 8192x8192x128 SIFT match + ratio test -> matched correspondences (on device) -> "
-                               "4096-iteration 7-point F-RANSAC and 4096-iteration P3P PnP-RANSAC (+ EPnP refit of its inliers) over them, per frame pair",
-                   "pairs_per_gpu_per_step": B, "parallelism": f"pairs sharded over {world} GPU(s), no collective"},
+        "config": {"workload": wl, "pairs_per_step": B if shard else None, "pairs_per_gpu_per_step": None if shard else B,
+                   "mode": args.mode, "parallelism": par_note, "process_group": f"nccl (RCCL), world size {world}"},
         "ransac_scoring": {"metric": "RANSAC hypotheses x points scored/sec",
-                           "value": evals_f / avg["score_fund"],
+                           "value": evals_f / t_f,
                            "unit": "evaluations/s per GPU inside the F scoring kernel (models that exist x correspondences)",
-                           "pnp_value": evals_p / avg["score_pnp"],
+                           "pnp_value": evals_p / t_p,
                            "whole_job_evals_per_s": (evals_f + evals_p) * world * args.steps / dt,
                            "matches_per_pair": float(n_match.mean()),
                            "models_scored_per_pair": {"fund": n_models_f / B, "pnp": n_models_p / B},
@@ -308,12 +410,33 @@ def main():
         "device": prop.name, "cus": cus,
     }
     if rank == 0:
-        line["drop_in_latency"] = drop_in_latency() if (world == 1 and not args.no_latency) else None
-        line["cpu_baseline"] = cpu_baseline() if (world == 1 and not args.no_cpu) else None
+        solo = world == 1 and args.config == "cfg4"
+        line["drop_in_latency"] = drop_in_latency(cfg) if (solo and not args.no_latency) else None
+        line["cpu_baseline"] = cpu_baseline(cfg) if (world == 1 and not args.no_cpu) else None
         print(json.dumps(line), flush=True)
-    if dist:
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg4")
+    ap.add_argument("--mode", choices=["weak", "shard"], default="weak")
+    ap.add_argument("--pairs", type=int, default=0, help="frame pairs per GPU per step (weak) / per step (shard); 0 = the config's default")
+    ap.add_argument("--inproc", action="store_true", help="be the single rank in this process (for profilers)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-latency", action="store_true",
+                    help="skip the single-pair drop_in_latency leg (profiling runs: keeps rocprofv3's per-kernel "
+                         "averages to the launches of the steps)")
+    args = ap.parse_args()
+    if "RANK" in os.environ or args.inproc:
+        return worker(args)
+    return launcher(args, sys.argv[1:])
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -166,6 +166,33 @@ int vo_ransac_batch(int kind, const int32_t* samples, int H, const void* pts, co
                     double* best_model, double* best_rvec, uint8_t* mask, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* One vo_ransac_batch over several GPUs (the hypothesis range of every problem is split over
+ * the ranks, correspondences are replicated).  No counterpart in the reference, which is single-process;
+ * the three calls reproduce vo_ransac_batch(first_block = 0) bit for bit:
+ *   1. vo_ransac_slice_counts  every rank: solve + score iterations [h_lo, h_hi) of all `batch` problems into
+ *      its workspace (same size and layout as vo_ransac_batch's; vo_ransac_layout gives the byte offsets of
+ *      the nmodels table, batch x H int32, and of the counts table, batch x H x width int32, and width);
+ *   2. the caller exchanges the [h_lo, h_hi) slices of both tables between the ranks (ONE all_gather for
+ *      the whole batch; visual_odometry_amd/parallel.py) and writes the others' slices into its own tables;
+ *   3. vo_ransac_slice_finish  every rank: the replay of OpenCV's sequential bookkeeping over the complete
+ *      tables (replicated, so every rank gets the same `result`), then best_model / best_rvec = the
+ *      winner's model where this rank solved it (best iteration in [h_lo, h_hi)) and all-zero bytes
+ *      elsewhere, so that an integer SUM all-reduce of the raw 8-byte words leaves the winner's bits on
+ *      every rank;
+ *   4. vo_ransac_mask_models   mask[b] = inliers of best_model[b] (batch x 9 | 12 f64) for problems with
+ *      result[4b] >= 0, zeros otherwise.
+ * offsets_host: 4 x size_t = {nmodels offset, counts offset, width, total bytes}. */
+int vo_ransac_layout(int kind, int H, int batch, size_t* offsets_host);
+int vo_ransac_slice_counts(int kind, const int32_t* samples, int H, int h_lo, int h_hi, const void* pts,
+                           const float* img, const double* K4_host, int N, const int32_t* n_dev, int batch,
+                           float thr2, void* workspace, size_t workspace_bytes, void* stream);
+int vo_ransac_slice_finish(int kind, int H, int h_lo, int h_hi, int N, const int32_t* n_dev, int batch,
+                           double confidence, int max_iters, void* workspace, size_t workspace_bytes,
+                           int32_t* result, double* best_model, double* best_rvec, void* stream);
+int vo_ransac_mask_models(int kind, const double* best_model, const int32_t* result, const void* pts,
+                          const float* img, const double* K4_host, int N, const int32_t* n_dev, int batch,
+                          float thr2, uint8_t* mask, void* stream);
+
 /* vo_ransac_batch for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments,
  * results and kernels as vo_ransac_batch, minus the workspace: the scratch memory (model slots,

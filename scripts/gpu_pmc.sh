@@ -4,7 +4,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 tag=$1; shift
 mkdir -p gpurun_out
-timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-latency > gpurun_out/pmc_$tag.log 2>&1 || { tail -20 gpurun_out/pmc_$tag.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag -o pmc -- python3 bench.py --inproc --steps 2 --warmup 1 --no-cpu --no-latency > gpurun_out/pmc_$tag.log 2>&1 || { tail -20 gpurun_out/pmc_$tag.log; exit 1; }
 f=$(find gpurun_out/pmc_$tag -name '*counter_collection.csv' | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections

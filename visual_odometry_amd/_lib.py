@@ -56,6 +56,10 @@ _SIGNATURES = {
     "vo_ransac_workspace_bytes": (_sz, [_i, _i, _i]),
     "vo_ransac_batch": (_i, [_i, _vp, _i, _vp, _vp, C.POINTER(_d), _i, _vp, _i, _f, _d, _i, _i, _vp, _vp, _vp, _vp,
                              _vp, _sz, _vp]),
+    "vo_ransac_layout": (_i, [_i, _i, _i, _vp]),
+    "vo_ransac_slice_counts": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, C.POINTER(_d), _i, _vp, _i, _f, _vp, _sz, _vp]),
+    "vo_ransac_slice_finish": (_i, [_i, _i, _i, _i, _i, _vp, _i, _d, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "vo_ransac_mask_models": (_i, [_i, _vp, _vp, _vp, _vp, C.POINTER(_d), _i, _vp, _i, _f, _vp, _vp]),
     "vo_ransac_static_max_bytes": (_sz, []),
     "vo_ransac_batch_static": (_i, [_i, _vp, _i, _vp, _vp, C.POINTER(_d), _i, _vp, _i, _f, _d, _i, _i, _vp, _vp, _vp, _vp,
                                     _vp]),
@@ -104,8 +108,14 @@ def check(rc: int, what: str = "") -> None:
 _device_ok = {}
 
 
-def require_device(device: int = 0) -> None:
-    """Fail loudly unless a gfx950 GPU is usable through the loaded library."""
+def require_device(device: "int | None" = None) -> None:
+    """Fail loudly unless a gfx950 GPU is usable through the loaded library.  device=None checks the
+    current device (the one the entry points launch on), never another rank's GPU."""
+    if device is None:
+        if not torch.cuda.is_available():
+            load()
+            raise VoError("no HIP device visible to torch: the MI355X path has no CPU fallback")
+        device = torch.cuda.current_device()
     if not _device_ok.get(device):
         lib = load()
         if not torch.cuda.is_available():

@@ -43,6 +43,13 @@ int vo_launch_mask_best(int kind, const double* models, int slots_per_problem, i
                         const double* aux, int aux_w, double* best_aux, const int32_t* result, const void* pts,
                         const float* img, const int32_t* n_dev, int N, int batch, const double* K4, float thr2,
                         uint8_t* mask, double* best_model, hipStream_t s);
+// best_model[b] (and best_aux[b]) = the replay winner's model if its iteration lies in [own_lo, own_hi), else zeros
+int vo_launch_select_owned(int kind, const double* models, int slots_per_problem, int slots_per_sample, const double* aux,
+                           int aux_w, double* best_aux, const int32_t* result, int batch, int own_lo, int own_hi,
+                           double* best_model, hipStream_t s);
+// mask[b] from best_model[b] (batch x 9|12) for the problems with result[4b] >= 0, zeros otherwise
+int vo_launch_mask_direct(int kind, const double* best_model, const int32_t* result, const void* pts, const float* img,
+                          const int32_t* n_dev, int N, int batch, const double* K4, float thr2, uint8_t* mask, hipStream_t s);
 int vo_launch_solve_7pt(const int32_t* samples, int H, int per, const float* pts, int N, const int32_t* n_dev,
                         double* models, int32_t* nmodels, int32_t* list, int32_t* nlist, int h0, int hlen,
                         const int32_t* prev, hipStream_t s);

@@ -295,6 +295,96 @@ extern "C" int vo_ransac_batch(int kind, const int32_t* samples, int H, const vo
                                n_dev, N, batch, K4_host, thr2, mask, best_model, s);
 }
 
+// ---- hypothesis-sharded form (one RANSAC batch over several GPUs) -----------------
+// Rank r solves and scores iterations [h_lo, h_hi) of every problem into the SAME workspace layout
+// vo_ransac_batch uses; the ranks exchange their slices of the count tables (one all_gather on the
+// host side, visual_odometry_amd/parallel.py), after which every rank holds the complete tables and
+// vo_ransac_slice_finish replays them -- replicated, so every rank gets OpenCV's sequential answer.
+extern "C" int vo_ransac_layout(int kind, int H, int batch, size_t* offsets_host)
+{
+    VO_CHECK_ARG(kind >= 0 && kind <= 2 && H > 0 && batch > 0 && offsets_host, VO_EINVAL, "vo_ransac_layout: bad arguments");
+    const RansacWs w = carve(nullptr, kWidth[kind], kMw[kind], kAux[kind], H, batch);
+    offsets_host[0] = (size_t)((char*)w.nmodels - (char*)nullptr);
+    offsets_host[1] = (size_t)((char*)w.counts - (char*)nullptr);
+    offsets_host[2] = (size_t)kWidth[kind];
+    offsets_host[3] = w.bytes;
+    return VO_OK;
+}
+
+extern "C" int vo_ransac_slice_counts(int kind, const int32_t* samples, int H, int h_lo, int h_hi, const void* pts,
+                                      const float* img, const double* K4_host, int N, const int32_t* n_dev, int batch,
+                                      float thr2, void* workspace, size_t workspace_bytes, void* stream)
+{
+    VO_CHECK_ARG(kind >= 0 && kind <= 2, VO_EINVAL, "vo_ransac_slice_counts: kind must be 0 (F), 1 (E) or 2 (PnP)");
+    VO_CHECK_ARG(H > 0 && N > 0 && batch >= 0 && h_lo >= 0 && h_lo <= h_hi && h_hi <= H, VO_EINVAL,
+                 "vo_ransac_slice_counts: bad sizes (H %d, slice [%d, %d), N %d, batch %d)", H, h_lo, h_hi, N, batch);
+    if (batch == 0) return VO_OK;
+    VO_CHECK_ARG(samples && pts, VO_EINVAL, "vo_ransac_slice_counts: null pointer");
+    VO_CHECK_ARG(kind != VO_KIND_PNP || (img && K4_host && ((uintptr_t)img & 7) == 0), VO_EINVAL,
+                 "vo_ransac_slice_counts: PnP needs img (8-byte aligned) and K4_host");
+    VO_CHECK_ARG(kind != VO_KIND_FUND || ((uintptr_t)pts & 15) == 0, VO_EINVAL, "vo_ransac_slice_counts: pts must be 16-byte aligned");
+    VO_CHECK_ARG((long)H * batch <= 2147483647L / 16 && batch <= 65535, VO_ESIZE, "vo_ransac_slice_counts: H x batch too large");
+    const int width = kWidth[kind], mw = kMw[kind], aux_w = kAux[kind];
+    const RansacWs w = carve(workspace, width, mw, aux_w, H, batch);
+    VO_CHECK_ARG(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= w.bytes, VO_EWORKSPACE,
+                 "vo_ransac_slice_counts: workspace of %zu bytes (16-byte aligned) required, got %zu", w.bytes, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    VO_HIP_TRY(hipMemsetAsync((char*)workspace + w.zero_from, 0, w.zero_bytes, s));
+    const int hlen = h_hi - h_lo;
+    if (hlen == 0) return VO_OK;
+    int rc;
+    if (kind == VO_KIND_FUND)
+        rc = vo_launch_solve_7pt(samples, H * batch, H, (const float*)pts, N, n_dev, w.models, w.nmodels, w.list, w.nlist, h_lo,
+                                 hlen, nullptr, s);
+    else if (kind == VO_KIND_ESS)
+        rc = vo_launch_solve_5pt(samples, H * batch, H, (const double*)pts, N, n_dev, w.models, w.nmodels, w.list, w.nlist, h_lo,
+                                 hlen, nullptr, s);
+    else
+        rc = vo_launch_solve_p3p(samples, H * batch, H, (const float*)pts, img, K4_host, N, n_dev, w.models, w.aux, w.nmodels,
+                                 w.list, w.nlist, h_lo, hlen, nullptr, s);
+    if (rc != VO_OK) return rc;
+    vo_prof_begin(VO_STAGE_SCORE, kind, s);
+    rc = vo_launch_score(kind, w.models, nullptr, w.list, nullptr, w.nlist, H * width, pts, img, n_dev, N, batch, K4_host,
+                         thr2, w.counts, hlen * width, s);
+    vo_prof_end(VO_STAGE_SCORE, s);
+    return rc;
+}
+
+extern "C" int vo_ransac_slice_finish(int kind, int H, int h_lo, int h_hi, int N, const int32_t* n_dev, int batch,
+                                      double confidence, int max_iters, void* workspace, size_t workspace_bytes,
+                                      int32_t* result, double* best_model, double* best_rvec, void* stream)
+{
+    VO_CHECK_ARG(kind >= 0 && kind <= 2, VO_EINVAL, "vo_ransac_slice_finish: kind must be 0 (F), 1 (E) or 2 (PnP)");
+    VO_CHECK_ARG(H > 0 && N > 0 && batch >= 0 && h_lo >= 0 && h_lo <= h_hi && h_hi <= H, VO_EINVAL,
+                 "vo_ransac_slice_finish: bad sizes");
+    if (batch == 0) return VO_OK;
+    VO_CHECK_ARG(result && best_model, VO_EINVAL, "vo_ransac_slice_finish: null pointer");
+    VO_CHECK_ARG(confidence > 0 && confidence < 1, VO_EINVAL, "vo_ransac_slice_finish: confidence must be in (0,1)");
+    const int width = kWidth[kind], mw = kMw[kind], aux_w = kAux[kind];
+    const RansacWs w = carve(workspace, width, mw, aux_w, H, batch);
+    VO_CHECK_ARG(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= w.bytes, VO_EWORKSPACE,
+                 "vo_ransac_slice_finish: workspace of %zu bytes (16-byte aligned) required, got %zu", w.bytes, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = vo_launch_replay(w.counts, w.nmodels, H, width, N, n_dev, kModelPoints[kind], confidence, max_iters, batch,
+                                    result, s);
+    if (rc != VO_OK) return rc;
+    return vo_launch_select_owned(kind, w.models, H * width, width, aux_w ? w.aux : nullptr, aux_w, best_rvec, result, batch,
+                                  h_lo, h_hi, best_model, s);
+}
+
+extern "C" int vo_ransac_mask_models(int kind, const double* best_model, const int32_t* result, const void* pts,
+                                     const float* img, const double* K4_host, int N, const int32_t* n_dev, int batch,
+                                     float thr2, uint8_t* mask, void* stream)
+{
+    VO_CHECK_ARG(kind >= 0 && kind <= 2 && N > 0 && batch >= 0, VO_EINVAL, "vo_ransac_mask_models: bad arguments");
+    if (batch == 0) return VO_OK;
+    VO_CHECK_ARG(best_model && result && pts && mask, VO_EINVAL, "vo_ransac_mask_models: null pointer");
+    VO_CHECK_ARG(kind != VO_KIND_PNP || (img && K4_host && ((uintptr_t)img & 7) == 0), VO_EINVAL,
+                 "vo_ransac_mask_models: PnP needs img (8-byte aligned) and K4_host");
+    VO_CHECK_ARG(kind != VO_KIND_FUND || ((uintptr_t)pts & 15) == 0, VO_EINVAL, "vo_ransac_mask_models: pts must be 16-byte aligned");
+    return vo_launch_mask_direct(kind, best_model, result, pts, img, n_dev, N, batch, K4_host, thr2, mask, (hipStream_t)stream);
+}
+
 // ---- the allocation-free variant's workspace: one fixed array per GPU, in the code object -------
 // `scratch` is a host-side stand-in here, not a device address: host code only ever hands it to
 // hipGetSymbolAddress (once per device, with that device current) and uses the pointer that comes back.

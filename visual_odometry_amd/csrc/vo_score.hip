@@ -440,9 +440,27 @@ struct MaskArgs {
     const double* aux;         // batch x (slots_per_problem) x aux_w, may be null (P3P rotation vectors)
     double* best_aux;          // batch x aux_w
     int slots_per_problem, slots_per_sample, aux_w, N;
+    int direct;                // 1: models is batch x MW, one model per problem (the winner itself)
     float thr2;
     double fx, fy, cx, cy;
 };
+
+// best_model[b] / best_aux[b] = the winner's model where this rank solved it (iteration in [own_lo, own_hi)),
+// zeros elsewhere: summed over the ranks as integers, every rank ends up with the winner's bits.
+__global__ __launch_bounds__(64)
+void select_owned_kernel(const double* __restrict__ models, const double* __restrict__ aux, const int32_t* __restrict__ result,
+                         int slots_per_problem, int slots_per_sample, int mw, int aux_w, int own_lo, int own_hi, int batch,
+                         double* __restrict__ best_model, double* __restrict__ best_aux)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const int best_iter = result[4 * b], best_k = result[4 * b + 1];
+    const bool own = best_iter >= own_lo && best_iter < own_hi && best_k >= 0;
+    const size_t slot = (size_t)b * slots_per_problem + (own ? best_iter * slots_per_sample + best_k : 0);
+    for (int k = 0; k < mw; ++k) best_model[(size_t)b * mw + k] = own ? models[slot * mw + k] : 0.;
+    if (aux && best_aux)
+        for (int k = 0; k < aux_w; ++k) best_aux[(size_t)b * aux_w + k] = own ? aux[slot * aux_w + k] : 0.;
+}
 
 template <int KIND>
 __global__ __launch_bounds__(256)
@@ -453,7 +471,8 @@ void mask_best_kernel(const MaskArgs a)
     const int n = a.n_dev ? min(a.n_dev[b], a.N) : a.N;
     const int best_iter = a.result[4 * b], best_k = a.result[4 * b + 1];
     const bool have = best_iter >= 0 && best_k >= 0;
-    const size_t slot = (size_t)b * a.slots_per_problem + (have ? best_iter * a.slots_per_sample + best_k : 0);
+    const size_t slot = a.direct ? (size_t)b
+                                 : (size_t)b * a.slots_per_problem + (have ? best_iter * a.slots_per_sample + best_k : 0);
     double M[MW];
 #pragma unroll
     for (int k = 0; k < MW; ++k) M[k] = have ? a.models[slot * MW + k] : 0.;
@@ -565,12 +584,41 @@ int vo_launch_mask_best(int kind, const double* models, int slots_per_problem, i
     MaskArgs a;
     a.models = models; a.result = result; a.pts = pts; a.img = (const float2*)img; a.n_dev = n_dev; a.mask = mask;
     a.best_model = best_model; a.aux = aux; a.best_aux = best_aux; a.aux_w = aux_w;
-    a.slots_per_problem = slots_per_problem; a.slots_per_sample = slots_per_sample; a.N = N; a.thr2 = thr2;
+    a.slots_per_problem = slots_per_problem; a.slots_per_sample = slots_per_sample; a.N = N; a.thr2 = thr2; a.direct = 0;
     a.fx = K4 ? K4[0] : 0; a.fy = K4 ? K4[1] : 0; a.cx = K4 ? K4[2] : 0; a.cy = K4 ? K4[3] : 0;
     const dim3 grid(vo_ceil_div(N > 0 ? N : 1, 256), batch);
     if (kind == kFund) hipLaunchKernelGGL(mask_best_kernel<kFund>, grid, dim3(256), 0, s, a);
     else if (kind == kEss) hipLaunchKernelGGL(mask_best_kernel<kEss>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(mask_best_kernel<kPnp>, grid, dim3(256), 0, s, a);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}
+
+int vo_launch_mask_direct(int kind, const double* best_model, const int32_t* result, const void* pts, const float* img,
+                          const int32_t* n_dev, int N, int batch, const double* K4, float thr2, uint8_t* mask, hipStream_t s)
+{
+    if (batch == 0) return VO_OK;
+    MaskArgs a;
+    a.models = best_model; a.result = result; a.pts = pts; a.img = (const float2*)img; a.n_dev = n_dev; a.mask = mask;
+    a.best_model = nullptr; a.aux = nullptr; a.best_aux = nullptr; a.aux_w = 0;
+    a.slots_per_problem = 1; a.slots_per_sample = 1; a.N = N; a.thr2 = thr2; a.direct = 1;
+    a.fx = K4 ? K4[0] : 0; a.fy = K4 ? K4[1] : 0; a.cx = K4 ? K4[2] : 0; a.cy = K4 ? K4[3] : 0;
+    const dim3 grid(vo_ceil_div(N > 0 ? N : 1, 256), batch);
+    if (kind == kFund) hipLaunchKernelGGL(mask_best_kernel<kFund>, grid, dim3(256), 0, s, a);
+    else if (kind == kEss) hipLaunchKernelGGL(mask_best_kernel<kEss>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(mask_best_kernel<kPnp>, grid, dim3(256), 0, s, a);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}
+
+int vo_launch_select_owned(int kind, const double* models, int slots_per_problem, int slots_per_sample, const double* aux,
+                           int aux_w, double* best_aux, const int32_t* result, int batch, int own_lo, int own_hi,
+                           double* best_model, hipStream_t s)
+{
+    if (batch == 0) return VO_OK;
+    const int mw = kind == kPnp ? 12 : 9;
+    hipLaunchKernelGGL(select_owned_kernel, dim3(vo_ceil_div(batch, 64)), dim3(64), 0, s, models, aux, result, slots_per_problem,
+                       slots_per_sample, mw, aux_w, own_lo, own_hi, batch, best_model, best_aux);
     VO_LAUNCH_CHECK();
     return VO_OK;
 }

@@ -30,6 +30,9 @@ def _dev(t: torch.Tensor, dtype: torch.dtype, name: str) -> torch.Tensor:
         raise _lib.VoError(f"{name} must live on the GPU")
     if t.dtype != dtype:
         raise _lib.VoError(f"{name} must be {dtype}, got {t.dtype}")
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        raise _lib.VoError(f"{name} lives on cuda:{t.device.index} but the current device is "
+                           f"cuda:{torch.cuda.current_device()}: launches go to the current device's stream")
     return t.contiguous()
 
 
@@ -304,6 +307,97 @@ def ransac_batch(kind: int, samples: torch.Tensor, pts: torch.Tensor, threshold:
                                    _ptr(workspace), workspace.numel() * workspace.element_size(), _stream()),
                "vo_ransac_batch")
     return result, best, rvec, mask
+
+
+def _ransac_problem(kind, samples, pts, img, K, n_dev):
+    """shape checks shared by the sliced entry points -> (samples, pts, img ptr, K4, n_dev, B, H, N)"""
+    m = _SAMPLE_WIDTH[kind]
+    samples = _dev(samples, torch.int32, "samples")
+    if samples.ndim != 3 or samples.shape[2] != m:
+        raise _lib.VoError(f"samples must be (B,H,{m})")
+    B, H = samples.shape[0], samples.shape[1]
+    pts = _dev(pts, torch.float64 if kind == KIND_ESS else torch.float32, "pts")
+    last = 3 if kind == KIND_PNP else 4
+    if pts.ndim != 3 or pts.shape[0] != B or pts.shape[2] != last:
+        raise _lib.VoError(f"pts must be (B,N,{last})")
+    N = pts.shape[1]
+    img_t = k4 = None
+    if kind == KIND_PNP:
+        img_t = _dev(img, torch.float32, "img")
+        if tuple(img_t.shape) != (B, N, 2):
+            raise _lib.VoError("img must be (B,N,2)")
+        k4 = _K4(K)
+    nd = None if n_dev is None else _dev(n_dev, torch.int32, "n_dev")
+    return samples, pts, img_t, k4, nd, B, H, N
+
+
+def ransac_layout(kind: int, H: int, batch: int):
+    """-> (byte offset of the nmodels table, of the counts table, models per sample, workspace bytes)"""
+    off = (C.c_size_t * 4)()
+    _lib.check(_lib.load().vo_ransac_layout(int(kind), int(H), int(batch), C.addressof(off)), "vo_ransac_layout")
+    return int(off[0]), int(off[1]), int(off[2]), int(off[3])
+
+
+def ransac_tables(kind: int, H: int, batch: int, workspace: torch.Tensor):
+    """Views of the count tables inside a vo_ransac_* workspace: counts (B,H,width) i32, nmodels (B,H) i32."""
+    o_nm, o_cnt, width, total = ransac_layout(kind, H, batch)
+    flat = workspace.reshape(-1).view(torch.uint8)
+    if flat.numel() < total:
+        raise _lib.VoError("ransac_tables: workspace too small")
+    nm = flat[o_nm:o_nm + 4 * batch * H].view(torch.int32).reshape(batch, H)
+    cnt = flat[o_cnt:o_cnt + 4 * batch * H * width].view(torch.int32).reshape(batch, H, width)
+    return cnt, nm
+
+
+def ransac_slice_counts(kind: int, samples: torch.Tensor, pts: torch.Tensor, threshold: float, h_lo: int, h_hi: int,
+                        img: Optional[torch.Tensor] = None, K=None, n_dev: Optional[torch.Tensor] = None,
+                        workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Solve + score iterations [h_lo, h_hi) of every problem into `workspace` (allocated when None or too small;
+    returned).  See vo_ransac_slice_counts in include/vo_hip.h."""
+    _lib.require_device()
+    lib = _lib.load()
+    samples, pts, img_t, k4, nd, B, H, N = _ransac_problem(kind, samples, pts, img, K, n_dev)
+    need = lib.vo_ransac_workspace_bytes(kind, H, B)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty((need,), dtype=torch.uint8, device=samples.device)
+    _lib.check(lib.vo_ransac_slice_counts(kind, _ptr(samples), H, int(h_lo), int(h_hi), _ptr(pts), _ptr(img_t), k4, N, _ptr(nd),
+                                          B, thr2_of(threshold), _ptr(workspace),
+                                          workspace.numel() * workspace.element_size(), _stream()), "vo_ransac_slice_counts")
+    return workspace
+
+
+def ransac_slice_finish(kind: int, H: int, h_lo: int, h_hi: int, N: int, batch: int, confidence: float, max_iters: int,
+                        workspace: torch.Tensor, n_dev: Optional[torch.Tensor] = None):
+    """Replay over the complete tables of `workspace` -> result (B,4) i32, best_model (B,9|12) f64 and best_rvec
+    (B,3) f64 | None, the latter two zero unless this rank solved the winning iteration."""
+    _lib.require_device()
+    dev = workspace.device
+    nd = None if n_dev is None else _dev(n_dev, torch.int32, "n_dev")
+    result = torch.empty((batch, 4), dtype=torch.int32, device=dev)
+    best = torch.empty((batch, 12 if kind == KIND_PNP else 9), dtype=torch.float64, device=dev)
+    rvec = torch.empty((batch, 3), dtype=torch.float64, device=dev) if kind == KIND_PNP else None
+    _lib.check(_lib.load().vo_ransac_slice_finish(kind, int(H), int(h_lo), int(h_hi), int(N), _ptr(nd), int(batch),
+                                                  float(confidence), int(max_iters), _ptr(workspace),
+                                                  workspace.numel() * workspace.element_size(), _ptr(result), _ptr(best),
+                                                  _ptr(rvec), _stream()), "vo_ransac_slice_finish")
+    return result, best, rvec
+
+
+def ransac_mask_models(kind: int, best_model: torch.Tensor, result: torch.Tensor, pts: torch.Tensor, threshold: float,
+                       img: Optional[torch.Tensor] = None, K=None, n_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """mask (B,N) u8 of best_model[b] over problem b's correspondences (zeros where result[b,0] < 0)."""
+    _lib.require_device()
+    best_model = _dev(best_model, torch.float64, "best_model"); result = _dev(result, torch.int32, "result")
+    pts = _dev(pts, torch.float64 if kind == KIND_ESS else torch.float32, "pts")
+    B, N = pts.shape[0], pts.shape[1]
+    img_p = k4 = None
+    if kind == KIND_PNP:
+        img_p, k4 = _ptr(_dev(img, torch.float32, "img")), _K4(K)
+    nd = None if n_dev is None else _dev(n_dev, torch.int32, "n_dev")
+    mask = torch.empty((B, N), dtype=torch.uint8, device=pts.device)
+    _lib.check(_lib.load().vo_ransac_mask_models(kind, _ptr(best_model), _ptr(result), _ptr(pts), img_p, k4, N, _ptr(nd), B,
+                                                 thr2_of(threshold), _ptr(mask), _stream()), "vo_ransac_mask_models")
+    return mask
 
 
 def match_compact(idx: torch.Tensor, keep: torch.Tensor, kp_q: torch.Tensor, kp_t: torch.Tensor,

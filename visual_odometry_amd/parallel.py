@@ -67,8 +67,7 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
     assert local.shape[0] == hi - lo, "local slice does not match shard_bounds"
     pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: hi - lo] = local
-    out = torch.empty((world * width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad, group=_pg(group))
+    out = all_gather_stack(pad, group).reshape((world * width,) + tuple(local.shape[1:]))
     parts = []
     for r in range(world):
         a, b = shard_bounds(n_total, r, world)
@@ -128,3 +127,132 @@ def sharded_ransac(n_iters: int, max_models: int, model_width: int,
     else:
         model = torch.empty((model_width,), dtype=models.dtype, device=models.device)
     return best_iter, best_k, max_good, niters, broadcast_from_owner(model, owner, group)
+
+
+# ------------------------------------------------------------------ batched, hypothesis-sharded RANSAC
+def _is_gloo(group) -> bool:
+    return dist.get_backend(_pg(group)) == "gloo"
+
+
+def _live(group) -> bool:
+    """True when `group` names a process group: the collectives below then run even with one rank (a one-rank
+    RCCL job, e.g. `bench.py --gpus 1`, goes through the same calls as an eight-rank one)."""
+    return group is not None and dist.is_available() and dist.is_initialized()
+
+
+def all_gather_stack(local: torch.Tensor, group=None) -> torch.Tensor:
+    """(world,) + local.shape: every rank's `local` (same shape and dtype everywhere), ONE collective.
+    RCCL gathers device tensors in place; under gloo (CPU tests, or several ranks on one GPU) device
+    tensors take the round trip through host memory."""
+    _, world = world_info(group)
+    if not _live(group):
+        return local[None]
+    local = local.contiguous()
+    if local.is_cuda and _is_gloo(group):
+        host = local.cpu()
+        out = torch.empty((world * host.shape[0],) + tuple(host.shape[1:]), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host, group=_pg(group))
+        return out.reshape((world,) + tuple(host.shape)).to(local.device)
+    # output laid out as the concatenation along dim 0 (the form every backend accepts), viewed as a stack
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local, group=_pg(group))
+    return out.reshape((world,) + tuple(local.shape))
+
+
+def all_reduce_sum_bits(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place integer SUM of the raw 8-byte words of `t` (f64 or i64).  With all-zero bytes on every rank
+    but one, every rank ends up with that rank's exact bit pattern (also for -0.0 and NaN payloads)."""
+    if not _live(group):
+        return t
+    bits = t.view(torch.int64)
+    if bits.is_cuda and _is_gloo(group):
+        host = bits.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=_pg(group))
+        bits.copy_(host)
+    else:
+        dist.all_reduce(bits, op=dist.ReduceOp.SUM, group=_pg(group))
+    return t
+
+
+def all_gather_dim1(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """local (B, n_local, ...) = this rank's shard_bounds(n_total) slice along dim 1 -> (B, n_total, ...)."""
+    rank, world = world_info(group)
+    if not _live(group):
+        return local
+    width = -(-n_total // world)
+    lo, hi = shard_bounds(n_total, rank, world)
+    assert local.shape[1] == hi - lo, "local slice does not match shard_bounds"
+    if hi - lo == width:
+        pad = local
+    else:
+        pad = torch.zeros((local.shape[0], width) + tuple(local.shape[2:]), dtype=local.dtype, device=local.device)
+        pad[:, : hi - lo] = local
+    g = all_gather_stack(pad, group)                        # (world, B, width, ...)
+    if n_total == world * width:
+        return g.transpose(0, 1).reshape((local.shape[0], n_total) + tuple(local.shape[2:]))
+    parts = []
+    for r in range(world):
+        a, b = shard_bounds(n_total, r, world)
+        parts.append(g[r][:, : b - a])
+    return torch.cat(parts, dim=1)
+
+
+class DeviceRansacBackend:
+    """The three per-rank steps of the sharded batch on the MI355X (visual_odometry_amd.ops)."""
+
+    def __init__(self):
+        from . import ops
+        self.ops = ops
+
+    def slice_counts(self, kind, samples, pts, threshold, lo, hi, img, K, n_dev, workspace):
+        ws = self.ops.ransac_slice_counts(kind, samples, pts, threshold, lo, hi, img=img, K=K, n_dev=n_dev, workspace=workspace)
+        counts, nmodels = self.ops.ransac_tables(kind, samples.shape[1], samples.shape[0], ws)
+        return counts, nmodels, ws
+
+    def slice_finish(self, kind, H, lo, hi, N, batch, confidence, max_iters, state, n_dev):
+        return self.ops.ransac_slice_finish(kind, H, lo, hi, N, batch, confidence, max_iters, state, n_dev=n_dev)
+
+    def mask_models(self, kind, best, result, pts, threshold, img, K, n_dev):
+        return self.ops.ransac_mask_models(kind, best, result, pts, threshold, img=img, K=K, n_dev=n_dev)
+
+
+def ransac_batch_sharded(kind: int, samples: torch.Tensor, pts: torch.Tensor, threshold: float, confidence: float,
+                         max_iters: int, img: Optional[torch.Tensor] = None, K=None, n_dev: Optional[torch.Tensor] = None,
+                         workspace: Optional[torch.Tensor] = None, group=WORLD, backend=None):
+    """ops.ransac_batch (first_block = 0) with the iteration range of EVERY problem of the batch split over the
+    ranks of `group`; all ranks pass identical inputs and receive identical outputs, bit for bit those of the
+    unsharded call:  result (B,4) i32, best_model (B,9|12) f64, best_rvec (B,3) f64 | None, mask (B,N) u8.
+
+    Per rank: solve + score its iterations (backend.slice_counts) -> ONE all_gather of the batch's count-table
+    slices (counts and nmodels packed in one int32 tensor) -> replicated replay of OpenCV's sequential
+    bookkeeping (backend.slice_finish) -> ONE integer-SUM all-reduce that hands every rank the winners' model
+    bits -> masks (backend.mask_models, replicated).  `backend` is DeviceRansacBackend unless a test
+    substitutes a CPU one."""
+    be = backend or DeviceRansacBackend()
+    rank, world = world_info(group)
+    B, H, N = samples.shape[0], samples.shape[1], pts.shape[1]
+    lo, hi = shard_bounds(H, rank, world)
+    counts, nmodels, state = be.slice_counts(kind, samples, pts, threshold, lo, hi, img, K, n_dev, workspace)
+    if _live(group):
+        width = counts.shape[2]
+        per = -(-H // world)
+        send = torch.zeros((B, per, width + 1), dtype=torch.int32, device=counts.device)
+        send[:, : hi - lo, :width] = counts[:, lo:hi]
+        send[:, : hi - lo, width] = nmodels[:, lo:hi]
+        got = all_gather_stack(send, group)                 # (world, B, per, width + 1)
+        for r in range(world):
+            if r == rank:
+                continue
+            a, b = shard_bounds(H, r, world)
+            counts[:, a:b] = got[r, :, : b - a, :width]
+            nmodels[:, a:b] = got[r, :, : b - a, width]
+    result, best, rvec = be.slice_finish(kind, H, lo, hi, N, B, confidence, max_iters, state, n_dev)
+    if _live(group):
+        if rvec is not None:
+            both = torch.cat([best, rvec], dim=1).contiguous()
+            all_reduce_sum_bits(both, group)
+            best, rvec = both[:, : best.shape[1]].contiguous(), both[:, best.shape[1]:].contiguous()
+        else:
+            all_reduce_sum_bits(best, group)
+    mask = be.mask_models(kind, best, result, pts, threshold, img, K, n_dev)
+    return result, best, rvec, mask

@@ -42,6 +42,24 @@ class PairBatchResult:
     p_samples: Optional[torch.Tensor] = None
     obj: Optional[torch.Tensor] = None           # (B,nq,3) f32 / (B,nq,2) f32: the PnP correspondences
     img: Optional[torch.Tensor] = None
+    desc_flags: Optional[torch.Tensor] = None    # (2,) i32 VO_DESC_BAD_* bits of the query / train descriptors: callers
+                                                 # MUST check it (check_descriptors) where they synchronise anyway --
+                                                 # the int8 matcher is only exact for integer 0..255 rows of norm <= 1024
+
+    def check_descriptors(self) -> None:
+        """Raise VoError if the descriptor conversion flagged non-integer / out-of-range values or rows whose
+        norm exceeds 1024 (one host synchronisation).  The single-pair entry points raise by themselves."""
+        if self.desc_flags is None:
+            return
+        fq, ft = (int(v) for v in self.desc_flags.cpu())
+        if fq | ft:
+            what = []
+            if (fq | ft) & ops._lib.VO_DESC_BAD_VALUE:
+                what.append("descriptor values must be integers in [0, 255]")
+            if (fq | ft) & ops._lib.VO_DESC_BAD_NORM:
+                what.append("a descriptor row has L2 norm > 1024 (OpenCV's f32 sqrt keys could tie where the integer keys do not)")
+            raise ops._lib.VoError(f"batched matching: {'; '.join(what)} (query flags {fq}, train flags {ft}): "
+                                   "results would differ from cv.BFMatcher")
 
 
 _side = {}
@@ -93,7 +111,7 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
                      f_threshold: float, f_confidence: float, f_iters: int,
                      xyz_q: Optional[torch.Tensor] = None, K=None, p_threshold: float = 1.0, p_confidence: float = 0.9999,
                      p_iters: int = 0, first_block_f: int = 0, first_block_pnp: int = 0,
-                     workspace: Optional[torch.Tensor] = None, wait_pnp: bool = True) -> PairBatchResult:
+                     workspace: Optional[torch.Tensor] = None, wait_pnp: bool = True, group=None) -> PairBatchResult:
     """desc_* (B,n,128) f32 integer-valued, kp_* (B,n,2) f32, xyz_q (B,nq,3) f32 landmarks of the query
     keypoints (enables the PnP run when p_iters > 0).  first_block_*: see ops.ransac_batch (0 = evaluate all
     iterations at once).  Everything is enqueued on the current stream, except the PnP chain (P3P RANSAC +
@@ -104,7 +122,14 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
     Per pair the RANSAC runs see exactly the correspondences, in the order, that the reference's
     gathers would hand to cv2 -- so results equal the single-pair entry points'.  Pairs with fewer
     than 15 (F) / 5 (PnP) matches get no model (the reference's cv2 calls switch algorithm or fail
-    there)."""
+    there).
+
+    group (parallel.WORLD or a process group): ONE batch over several GPUs -- every rank passes the same
+    inputs and gets the same outputs; see match_and_ransac_sharded."""
+    if group is not None:
+        return match_and_ransac_sharded(desc_q, desc_t, kp_q, kp_t, ratio, f_threshold, f_confidence, f_iters, xyz_q=xyz_q, K=K,
+                                        p_threshold=p_threshold, p_confidence=p_confidence, p_iters=p_iters,
+                                        workspace=workspace, group=group, first_block_pnp=first_block_pnp)
     B, nq, nt = desc_q.shape[0], desc_q.shape[1], desc_t.shape[1]
     flags = torch.zeros((2,), dtype=torch.int32, device=desc_q.device)       # one fill for both conversions
     qi8, qn, _ = ops.desc_to_i8(desc_q.reshape(B * nq, 128), flags[0:1])
@@ -138,12 +163,87 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
     f_samples, _ = ops.gen_subsets_device(n_f, nq, 7, f_iters, c["pts4"])
     f_res, F, _, f_mask = ops.ransac_batch(ops.KIND_FUND, f_samples, c["pts4"], f_threshold, f_confidence, f_iters,
                                            n_dev=n_f, workspace=ws_f, first_block=first_block_f)
-    out = PairBatchResult(idx, d2, c["match_q"], c["match_t"], n, c["pts4"], f_res, F, f_mask, f_samples=f_samples)
+    out = PairBatchResult(idx, d2, c["match_q"], c["match_t"], n, c["pts4"], f_res, F, f_mask, f_samples=f_samples,
+                          desc_flags=flags)
     if do_pnp:
         out.pnp_done = side.record_event()
         if wait_pnp:
             main.wait_event(out.pnp_done)
         out.p_result, out.pose, out.rvec, out.p_mask, out.p_samples, out.pose_refined, out.p_ok = pnp_out
+        out.obj, out.img = c["obj"], c["img"]
+    return out
+
+
+def match_and_ransac_sharded(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Tensor, kp_t: torch.Tensor, ratio: float,
+                             f_threshold: float, f_confidence: float, f_iters: int,
+                             xyz_q: Optional[torch.Tensor] = None, K=None, p_threshold: float = 1.0,
+                             p_confidence: float = 0.9999, p_iters: int = 0, workspace: Optional[torch.Tensor] = None,
+                             group="world", first_block_pnp: int = 0, pnp_split: str = "pairs") -> PairBatchResult:
+    """match_and_ransac for ONE batch of frame pairs spread over the ranks of `group` (BASELINE
+    cfg4 "sharded over 2/4/8 GPUs"): every rank holds the same inputs and returns the same PairBatchResult,
+    bit for bit the unsharded one.
+      * matching: the query rows of every pair are split over the ranks (train rows replicated); one
+        all_gather of the (idx, d2) rows assembles the 2-NN table everywhere;
+      * ratio test, compaction, getSubset: replicated (cheap, O(nq));
+      * F-RANSAC: the iteration range of every problem is split over the ranks (parallel.ransac_batch_sharded:
+        one all_gather of count tables + one all-reduce of the winners); all iterations are evaluated (at the
+        reference's 0.1 px threshold OpenCV's loop runs them all anyway);
+      * PnP-RANSAC + EPnP refit: pnp_split="pairs" (default) deals whole problems to the ranks, keeping the
+        early-termination blocks (first_block_pnp), and gathers the packed results with one all_gather;
+        pnp_split="iterations" splits every problem's iteration range like the F run.
+    Everything runs on the current stream: with collectives on the path the PnP chain is not moved to a side
+    stream."""
+    from . import parallel as par
+    rank, world = par.world_info(group)
+    B, nq, nt = desc_q.shape[0], desc_q.shape[1], desc_t.shape[1]
+    flags = torch.zeros((2,), dtype=torch.int32, device=desc_q.device)
+    qlo, qhi = par.shard_bounds(nq, rank, world)
+    nql = qhi - qlo
+    qi8, qn, _ = ops.desc_to_i8(desc_q[:, qlo:qhi].reshape(B * nql, 128), flags[0:1])
+    ti8, tn, _ = ops.desc_to_i8(desc_t.reshape(B * nt, 128), flags[1:2])
+    do_pnp = p_iters > 0 and xyz_q is not None
+    ws_k, ws_f, ws_p = _split_workspace(workspace, nq, nt, f_iters, p_iters if do_pnp else 0, B)
+    idx_l, d2_l = ops.knn2(qi8.reshape(B, nql, 128), qn.reshape(B, nql), ti8.reshape(B, nt, 128), tn.reshape(B, nt), ws_k)
+    both = par.all_gather_dim1(torch.cat([idx_l, d2_l], dim=2), nq, group)           # (B, nq, 4)
+    idx, d2 = both[:, :, :2].contiguous(), both[:, :, 2:].contiguous()
+    keep, _ = ops.ratio_test(d2.reshape(B * nq, 2), ratio)
+    c = ops.match_compact(idx, keep.reshape(B, nq), kp_q, kp_t, xyz_q if p_iters > 0 else None)
+    n = c["n"]
+    n_f = torch.where(n >= 15, n, torch.zeros_like(n))
+    f_samples, _ = ops.gen_subsets_device(n_f, nq, 7, f_iters, c["pts4"])
+    f_res, F, _, f_mask = par.ransac_batch_sharded(ops.KIND_FUND, f_samples, c["pts4"], f_threshold, f_confidence, f_iters,
+                                                   n_dev=n_f, workspace=ws_f, group=group)
+    out = PairBatchResult(idx, d2, c["match_q"], c["match_t"], n, c["pts4"], f_res, F, f_mask, f_samples=f_samples,
+                          desc_flags=flags)
+    if do_pnp:
+        n_p = torch.where(n >= 5, n, torch.zeros_like(n))
+        p_samples, _ = ops.gen_subsets_device(n_p, nq, 4, p_iters, None)
+        if pnp_split == "iterations":
+            p_res, pose, rvec, p_mask = par.ransac_batch_sharded(ops.KIND_PNP, p_samples, c["obj"], p_threshold, p_confidence,
+                                                                 p_iters, img=c["img"], K=K, n_dev=n_p, workspace=ws_p, group=group)
+            refined, p_ok = ops.epnp_batch(c["obj"], c["img"], p_mask, K, n_dev=n_p, result=p_res)
+        else:
+            # by pairs: OpenCV's adaptive loop usually leaves a PnP problem after a few iterations, so splitting its
+            # iteration range buys nothing; every rank runs whole problems (with early-termination blocks) for its
+            # share of the pairs and ONE all_gather of the packed per-pair results makes them resident everywhere
+            blo, bhi = par.shard_bounds(B, rank, world)
+            sl = slice(blo, bhi)
+            if bhi > blo:
+                r_l, pose_l, rvec_l, mask_l = ops.ransac_batch(ops.KIND_PNP, p_samples[sl], c["obj"][sl], p_threshold, p_confidence,
+                                                               p_iters, img=c["img"][sl], K=K, n_dev=n_p[sl], workspace=ws_p,
+                                                               first_block=first_block_pnp)
+                ref_l, ok_l = ops.epnp_batch(c["obj"][sl], c["img"][sl], mask_l, K, n_dev=n_p[sl], result=r_l)
+                u8 = lambda t: t.contiguous().view(torch.uint8).reshape(bhi - blo, -1)
+                packed = torch.cat([u8(pose_l), u8(rvec_l), u8(ref_l), u8(r_l), u8(ok_l), mask_l], dim=1)
+            else:
+                packed = torch.empty((0, 27 * 8 + 5 * 4 + nq), dtype=torch.uint8, device=desc_q.device)
+            full = par.all_gather_rows(packed, B, group) if par._live(group) else packed
+            f64 = lambda a, b: full[:, a:b].contiguous().view(torch.float64)
+            i32 = lambda a, b: full[:, a:b].contiguous().view(torch.int32)
+            pose, rvec, refined = f64(0, 96), f64(96, 120), f64(120, 216)
+            p_res, p_ok, p_mask = i32(216, 232), i32(232, 236).reshape(B), full[:, 236:].contiguous()
+        out.p_result, out.pose, out.rvec, out.p_mask, out.p_samples, out.pose_refined, out.p_ok = (
+            p_res, pose, rvec, p_mask, p_samples, refined, p_ok)
         out.obj, out.img = c["obj"], c["img"]
     return out
 
@@ -156,6 +256,7 @@ def finish_small_pairs(res: PairBatchResult, f_threshold: float, f_confidence: f
     with exactly 7 matches keep "no model": OpenCV returns every 7-point solution stacked there, which a
     (B,9) model array cannot hold."""
     from . import ransac
+    res.check_descriptors()                      # this call synchronises anyway
     n = res.n_match.cpu().numpy()
     small = [int(b) for b in range(len(n)) if 8 <= n[b] <= 14]
     for b in small:
@@ -167,7 +268,8 @@ def finish_small_pairs(res: PairBatchResult, f_threshold: float, f_confidence: f
             res.f_mask[b, :n[b]] = torch.from_numpy(mask.ravel().astype("uint8")).to(res.f_mask.device)
         if F is not None:
             res.F[b] = torch.from_numpy(F.reshape(9)).to(res.F.device)
-        row = [info.best_iter, info.best_model, info.max_good if F is not None else 0, info.niters]
+        # no F (e.g. the LMedS winner has fewer than 7 inliers): "no model", so that pose_tail gives the identity
+        row = [info.best_iter, info.best_model, info.max_good, info.niters] if F is not None else [-1, -1, 0, info.niters]
         res.f_result[b] = torch.tensor(row, dtype=torch.int32, device=res.f_result.device)
     return len(small)
 

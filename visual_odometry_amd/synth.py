@@ -88,12 +88,14 @@ def pnp_scene(n: int, K: np.ndarray = K_MALAGA, size=(1024, 768), seed: int = 43
 
 
 def frame_pair(nq: int, nt: int, seed: int = 0, K: np.ndarray = K_MALAGA, size=(1024, 768), match_frac: float = 0.6,
-               desc_noise: float = 8.0, noise_px: float = 0.3):
+               desc_noise: float = 8.0, noise_px: float = 0.3, landmark_outlier_frac: float = 0.0):
     """Two synthetic frames as SIFT would describe them, with geometry behind the true matches:
     -> dict(q, t (n,128) f32 descriptors; kp_q (nq,2), kp_t (nt,2) f32 positions; xyz_q (nq,3) f32
     landmarks of the query keypoints in the query camera frame; R, t the relative pose; K).
     ~match_frac of the train features are noisy copies of query features placed at the projection of
-    the query's landmark; the rest is clutter at random positions."""
+    the query's landmark; the rest is clutter at random positions.  landmark_outlier_frac of the query
+    landmarks are replaced by unrelated points (stale or mis-triangulated landmarks: PnP outliers that the
+    descriptor match cannot see)."""
     rng = np.random.default_rng(seed)
     sc = two_view_scene(nq, K=K, size=size, seed=seed, noise_px=noise_px, outlier_frac=0.0)
     q = sift_like(nq, rng)
@@ -103,5 +105,8 @@ def frame_pair(nq: int, nt: int, seed: int = 0, K: np.ndarray = K_MALAGA, size=(
     t[dst] = np.clip(np.rint(q[src] + rng.normal(0.0, desc_noise, (nmatch, 128))), 0, 255).astype(np.float32)
     kp_t = np.stack([rng.uniform(0, size[0], nt), rng.uniform(0, size[1], nt)], axis=1).astype(np.float32)
     kp_t[dst] = sc["p2"][src]
-    return dict(q=q, t=t, kp_q=sc["p1"].astype(np.float32), kp_t=kp_t, xyz_q=sc["X"].astype(np.float32),
-                R=sc["R"], t_vec=sc["t"], K=K)
+    xyz = sc["X"].astype(np.float32)
+    if landmark_outlier_frac > 0:
+        bad = rng.permutation(nq)[:int(landmark_outlier_frac * nq)]
+        xyz[bad] = xyz[rng.permutation(nq)[:len(bad)]] + rng.normal(0, 1.0, (len(bad), 3)).astype(np.float32)
+    return dict(q=q, t=t, kp_q=sc["p1"].astype(np.float32), kp_t=kp_t, xyz_q=xyz, R=sc["R"], t_vec=sc["t"], K=K)
