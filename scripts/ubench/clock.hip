@@ -37,6 +37,28 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* stamps,
                 if (OP == 11) asm volatile("v_max_i32 %0, %0, %1" : "+v"(*(int*)&a[i]) : "v"(it));
                 if (OP == 12) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(*(int*)&a[i]) : "v"(it), "v"(si));
                 if (OP == 13) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"((double)m), "v"((double)c));
+                if (OP == 14) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(*(int*)&a[i]) : "v"(it));
+                if (OP == 15) asm volatile("v_lshrrev_b32 %0, 31, %0" : "+v"(*(int*)&a[i]));
+                if (OP == 16) asm volatile("v_add_co_u32 %0, vcc, %0, %0" : "+v"(*(int*)&a[i]) : : "vcc");
+                if (OP == 17) asm volatile("v_bfe_u32 %0, %0, 31, 1" : "+v"(*(int*)&a[i]));
+                if (OP == 18) asm volatile("v_mul_f32 %0, %0, %1 clamp" : "+v"(*(float*)&a[i]) : "v"(m));
+                if (OP == 19) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1" : : "v"(*(float*)&a[i]), "v"(m) : "s20", "s21");
+                if (OP == 20) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[i]) : "v"((double)m));
+                if (OP == 21) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a[i]) : "v"((double)c));
+                if (OP == 22) asm volatile("v_rcp_f64 %0, %0" : "+v"(a[i]));
+                if (OP == 23) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(*(float*)&a[i]) : "v"(a[(i + 1) & 7]));
+                if (OP == 24) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a[i]) : "v"(m));
+                if (OP == 25) asm volatile("v_rcp_f32 %0, %0" : "+v"(*(float*)&a[i]));
+                if (OP == 26) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(*(int*)&a[i]) : "v"(it), "v"(si));
+                if (OP == 27) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(*(int*)&a[i]) : "v"(it));
+                if (OP == 28) asm volatile("v_fma_f32 %0, %0, %1, |%2|" : "+v"(*(float*)&a[i]) : "v"(m), "v"(c));
+                if (OP == 29) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(*(float*)&a[i]) : "s"(m), "v"(c));
+                if (OP == 30) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(*(float*)&a[i]) : "v"(m), "v"(c));
+                if (OP == 31) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(*(float*)&a[i]) : "v"(c));
+                if (OP == 32) asm volatile("v_div_fmas_f64 %0, %0, %1, %2" : "+v"(a[i]) : "v"((double)m), "v"((double)c));
+                if (OP == 33) asm volatile("v_div_scale_f64 %0, vcc, %0, %1, %1" : "+v"(a[i]) : "v"((double)m) : "vcc");
+                if (OP == 34) asm volatile("v_div_fixup_f64 %0, %0, %1, %2" : "+v"(a[i]) : "v"((double)m), "v"((double)c));
+                if (OP == 35) asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(*(int*)&a[i]) : "v"(it));
             }
         }
     }
@@ -94,5 +116,11 @@ int main()
     run<1>("v_mul_f32", w); run<2>("v_min_f32", w); run<3>("v_cmp_lt_f32", w); run<4>("v_cndmask_b32", w);
     run<5>("v_addc_co_u32", w); run<6>("v_max3_i32", w); run<7>("v_lshl_add_u32", w); run<8>("v_med3_i32", w);
     run<9>("v_add_u32", w); run<10>("v_fma_f64", w); run<11>("v_max_i32", w); run<12>("v_or3_b32", w); run<13>("v_pk_fma_f32", w);
+    run<14>("v_alignbit_b32", w); run<15>("v_lshrrev_b32", w); run<16>("v_add_co_u32", w); run<17>("v_bfe_u32", w);
+    run<18>("v_mul_f32 clamp", w); run<19>("v_cmp_lt_f32 sgpr", w); run<20>("v_mul_f64", w); run<21>("v_add_f64", w);
+    run<22>("v_rcp_f64", w); run<23>("v_cvt_f32_f64", w); run<24>("v_cvt_f64_f32", w); run<25>("v_rcp_f32", w);
+    run<26>("v_and_or_b32", w); run<27>("v_lshl_or_b32", w); run<28>("v_fma_f32 |abs|", w); run<29>("v_fma_f32 sgpr", w);
+    run<30>("v_fmac_f32", w); run<31>("v_sub_f32", w); run<32>("v_div_fmas_f64", w); run<33>("v_div_scale_f64", w);
+    run<34>("v_div_fixup_f64", w); run<35>("v_bcnt_u32_b32", w);
     return 0;
 }

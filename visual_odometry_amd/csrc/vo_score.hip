@@ -191,6 +191,38 @@ __device__ __forceinline__ int fund_filter32(const FundFilter32& f, float x1, fl
     return 0;
 }
 
+// The same two tests with the verdicts left in SIGN BITS instead of compare results: on gfx950 a v_cmp_f32
+// costs 4.8 issue cycles and a v_cndmask 12 against 1.95 for a v_fma_f32 (scripts/ubench/clock.hip), so the
+// compare-and-select bookkeeping of fund_filter32 costs as much as 18 of its FMAs.  Here
+//   r_in  = lo - tlo dmin   (one FMA: the product is exact inside it)   sign bit set  <=>  sure inlier
+//   r_out = thi dmin - hi                                               sign bit set  <=>  sure outlier
+// and the caller shifts the two sign bits into per-lane bit strings (v_alignbit_b32).  An exact zero gives +0
+// (sign clear: "cannot tell"), a negative value that underflows gives -0 (sign set, correctly).  The sign of a
+// NaN is NOT reliable, so this form is only used where no NaN or Inf can arise: every coordinate of the
+// staged chunk finite and <= 2^20 in magnitude, the lane's model usable (fund_filter32_setup) and thr2 within
+// [2^-60, 2^40] -- then every intermediate is finite and far from f32 overflow (|a|,|b| <= 2^22, den <= 2^45,
+// |d| <= 2^43, d^2 <= 2^86, thi dmin <= 2^86).  Everything else goes through fund_filter32.
+__device__ __forceinline__ void fund_filter32_signs(const FundFilter32& f, float x1, float y1, float x2, float y2,
+                                                    uint32_t& in_bits, uint32_t& out_bits)
+{
+    const float* F = f.F;
+    const float a1 = __builtin_fmaf(F[0], x1, __builtin_fmaf(F[1], y1, F[2]));
+    const float b1 = __builtin_fmaf(F[3], x1, __builtin_fmaf(F[4], y1, F[5]));
+    const float c1 = __builtin_fmaf(F[6], x1, __builtin_fmaf(F[7], y1, F[8]));
+    const float den2 = __builtin_fmaf(a1, a1, b1 * b1);
+    const float d = __builtin_fmaf(x2, a1, __builtin_fmaf(y2, b1, c1));
+    const float a2 = __builtin_fmaf(F[0], x2, __builtin_fmaf(F[3], y2, F[6]));
+    const float b2 = __builtin_fmaf(F[1], x2, __builtin_fmaf(F[4], y2, F[7]));
+    const float den1 = __builtin_fmaf(a2, a2, b2 * b2);
+    const float dmin = fminf(den1, den2);
+    const float mm = __builtin_fmaf(f.eta2, fabsf(d), f.c);
+    const float lo = __builtin_fmaf(d, d, mm), nhi = __builtin_fmaf(-d, d, mm);   // nhi = -(d^2 - mm), same rounding
+    const float r_in = __builtin_fmaf(-f.tlo, dmin, lo);
+    const float r_out = __builtin_fmaf(f.thi, dmin, nhi);
+    in_bits = __builtin_amdgcn_alignbit(in_bits, __float_as_uint(r_in), 31);       // (in_bits << 1) | sign(r_in)
+    out_bits = __builtin_amdgcn_alignbit(out_bits, __float_as_uint(r_out), 31);
+}
+
 // EMEstimatorCallback::computeError: Sampson distance on normalised coordinates
 __device__ __forceinline__ float sampson_err(const double* E, double ax, double ay, double bx, double by)
 {
@@ -267,23 +299,28 @@ void score_kernel(const ScoreArgs a)
     if (p0 >= n || (int)(blockIdx.x * kThreads) >= nslots) return;      // block-uniform
     const int np = min(a.chunk, n - p0);
 
-    __shared__ double sscale[2][kThreads / 64];
+    __shared__ double sscale[3][kThreads / 64];
     if (KIND == kFund) {
         const float4* pts = (const float4*)a.pts + (size_t)b * a.N + p0;
         double p1 = 1., p2 = 1.;                   // chunk-wide bounds on max(|x|,|y|,1) of either image
+        bool tame = true;                          // every coordinate finite and <= 2^20: the sign-bit filter applies
         for (int i = threadIdx.x; i < np; i += kThreads) {
             const float4 v = pts[i];
             ((float4*)sp)[i] = v;                  // F keeps f32 points: exact in either precision
             const double q1 = fmax(fabs((double)v.x), fabs((double)v.y)), q2 = fmax(fabs((double)v.z), fabs((double)v.w));
             p1 = fmax(p1, q1);                     // a NaN point fails the filter by itself
             p2 = fmax(p2, q2);
+            tame = tame && fabsf(v.x) <= 0x1p20f && fabsf(v.y) <= 0x1p20f && fabsf(v.z) <= 0x1p20f && fabsf(v.w) <= 0x1p20f;
         }
         for (int o = 32; o; o >>= 1) {
             const double o1 = __shfl_xor(p1, o), o2 = __shfl_xor(p2, o);
             p1 = fmax(p1, o1);
             p2 = fmax(p2, o2);
         }
-        if ((threadIdx.x & 63) == 0) { sscale[0][threadIdx.x >> 6] = p1; sscale[1][threadIdx.x >> 6] = p2; }
+        tame = __all(tame);
+        if ((threadIdx.x & 63) == 0) {
+            sscale[0][threadIdx.x >> 6] = p1; sscale[1][threadIdx.x >> 6] = p2; sscale[2][threadIdx.x >> 6] = tame ? 1. : 0.;
+        }
     } else if (KIND == kEss) {
         const double* pts = (const double*)a.pts + ((size_t)b * a.N + p0) * 4;
         for (int i = threadIdx.x; i < np * 4; i += kThreads) sp[i] = pts[i];
@@ -309,12 +346,13 @@ void score_kernel(const ScoreArgs a)
     if (!__any(live)) return;                  // wave past the end of the model list (no barrier follows)
     int cnt = 0;
     if (KIND == kFund) {
-        double p1 = sscale[0][0], p2 = sscale[1][0];
+        double p1 = sscale[0][0], p2 = sscale[1][0], tame_chunk = sscale[2][0];
 #pragma unroll
         for (int w = 1; w < kThreads / 64; ++w) {
             const double o1 = sscale[0][w], o2 = sscale[1][w];
             p1 = fmax(p1, o1);
             p2 = fmax(p2, o2);
+            tame_chunk = fmin(tame_chunk, sscale[2][w]);
         }
         const FundFilter ff = fund_filter_setup(M, (double)a.thr2, p1, p2);
         const FundFilter32 f32 = fund_filter32_setup(M, a.thr2, p1, p2);
@@ -325,6 +363,10 @@ void score_kernel(const ScoreArgs a)
         // cannot tell (within rounding distance of the threshold, or degenerate), the exact
         // evaluation.  Lanes wait for each other only for the longest bit list of the block, about
         // one entry per block on image-like data.  A lane without a model (all-zero M) never asks.
+        // sign-bit form of tier 1 (see fund_filter32_signs) for full blocks of tame chunks; a lane whose model or
+        // threshold falls outside its domain takes every correspondence to tier 2 instead (force)
+        const bool fast = tame_chunk != 0.;                                         // workgroup-uniform
+        const uint32_t force = (__builtin_isinf(f32.eta2) || !(a.thr2 >= 0x1p-60f && a.thr2 <= 0x1p40f)) ? 0xffffffffu : 0u;
         for (int i0 = 0; i0 < np; i0 += 32) {
             const int nb = min(32, np - i0);
             uint32_t bits = 0;
@@ -334,7 +376,16 @@ void score_kernel(const ScoreArgs a)
                 cnt += verdict > 0;
                 bits = (bits << 1) | (uint32_t)(verdict == 0);
             };
-            if (nb == 32) {
+            if (nb == 32 && fast) {
+                uint32_t in_bits = 0, out_bits = 0;
+#pragma unroll VO_SCORE_G
+                for (int k = 0; k < 32; ++k) {
+                    const float4 v = spf[i0 + k];
+                    fund_filter32_signs(f32, v.x, v.y, v.z, v.w, in_bits, out_bits);
+                }
+                bits = ~(in_bits | out_bits) | force;
+                cnt += __popc(in_bits & ~force);
+            } else if (nb == 32) {
 #pragma unroll VO_SCORE_G
                 for (int k = 0; k < 32; ++k) tier1(k);
             } else {
