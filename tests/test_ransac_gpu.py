@@ -151,6 +151,105 @@ def test_score_and_mask_pnp(oracle_mod, dev, thr):
     assert np.array_equal(m, oracle_mod.find_inliers(oracle_mod.pnp_error(pm[b][:9], pm[b][9:], K, obj, img), thr)[1])
 
 
+def _pnp_models(o, obj, img, K, n_subs=300, seed=0):
+    """P3P solutions of random minimal samples (near-true and junk poses alike), as (H,12) [R|t] rows."""
+    pm = []
+    for s in o.gen_subsets(len(obj), 4, n_subs):
+        ns, rv, tv, R = o.p3p_kernel(obj[s], img[s], K)
+        if ns > 0:
+            pm.append(np.concatenate([R.reshape(9), tv]))
+    return np.array(pm)
+
+
+def _pnp_ref(o, models, K, obj, img, thr):
+    with np.errstate(all="ignore"):
+        return np.array([o.find_inliers(o.pnp_error(m[:9].reshape(3, 3), m[9:], K, obj, img), thr)[0] for m in models])
+
+
+def test_score_pnp_filter_at_every_boundary(oracle_mod, dev):
+    """The PnP count kernel decides most correspondences with a division-free f32 filter and takes the rest
+    through the exact f64 evaluation: put the threshold ON the reprojection error of many different points
+    (and one f32 ulp either side), for the best and for a mediocre pose."""
+    ps = synth.pnp_scene(1500, seed=21)
+    obj, img, K = ps["obj"], ps["img"], ps["K"]
+    pm = _pnp_models(oracle_mod, obj, img, K, 200)
+    counts = _pnp_ref(oracle_mod, pm, K, obj, img, 2.0)
+    checked = 0
+    for m in (pm[int(np.argmax(counts))], pm[len(pm) // 2]):
+        err = oracle_mod.pnp_error(m[:9].reshape(3, 3), m[9:], K, obj, img)
+        for e in np.sort(err)[5:1400:31]:
+            for t2 in (e, np.nextafter(e, np.float32(0)), np.nextafter(e, np.float32(np.inf))):
+                thr = float(np.sqrt(np.float64(t2)))
+                if np.float32(thr * thr) != t2 or not np.isfinite(t2):
+                    continue
+                cnt = ops.score_pnp(_d(m[None], dev), _d(obj, dev), _d(img, dev), K, thr).cpu().numpy()
+                assert cnt[0] == int((err <= t2).sum()), (thr, cnt[0])
+                checked += 1
+    assert checked > 40
+
+
+def test_score_pnp_filter_degenerate_and_scaled(oracle_mod, dev):
+    """Zero / NaN / Inf / absurdly scaled poses, poses whose third row vanishes (z == 0: OpenCV then projects
+    with z = 1), points on the camera plane, far-away and non-finite points: every such case must come out of
+    the exact evaluation (same counts as the scalar definition)."""
+    ps = synth.pnp_scene(700, seed=22)
+    obj, img, K = ps["obj"].copy(), ps["img"].copy(), ps["K"]
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    base = _pnp_models(oracle_mod, obj, img, K, 40)[:24]
+    extra = [np.zeros(12), np.full(12, np.nan), np.full(12, np.inf)]
+    for k in range(12):
+        m = base[k].copy(); m[k] = np.nan; extra.append(m)
+        m = base[k].copy(); m[k] = np.inf; extra.append(m)
+        m = base[k].copy(); m[k] = 0.0; extra.append(m)
+    # z == 0 for every point: x = X, y = Y, so points with X = (u - cx)/fx, Y = (v - cy)/fy are exact inliers
+    m = np.zeros(12); m[0] = 1.0; m[4] = 1.0; extra.append(m)
+    m = base[0].copy(); m[6:9] = 0.0; m[11] = 0.0; extra.append(m)
+    # z tiny but not zero, and z == 0 only on the plane Z = 0
+    m = base[1].copy(); m[6:9] *= 1e-12; m[11] *= 1e-12; extra.append(m)
+    m = np.zeros(12); m[0] = 1.0; m[4] = 1.0; m[8] = 1.0; extra.append(m)
+    scaled = [base[i] * s_ for i, s_ in enumerate([1e-300, 1e-160, 1e-100, 1e-30, 1e30, 1e100, 1e160, 1e300])]
+    mods = np.concatenate([base, np.array(extra), np.array(scaled)])
+    obj[40:60, 0] = (img[40:60, 0] - cx) / fx; obj[40:60, 1] = (img[40:60, 1] - cy) / fy     # inliers of the z == 0 poses
+    obj[60:80, 2] = 0.0                                                                         # on the plane Z = 0
+    seen, z0 = 0, len(base) + 3 + 36                          # z0: index of the first z == 0 pose
+    for scale, poison in ((1.0, False), (1.0, True), (1e3, False), (1e-3, False)):
+        o2 = (obj.astype(np.float64) * scale).astype(np.float32); i2 = img.copy()
+        if poison:
+            o2[3, 0] = np.nan; i2[10, 1] = np.inf; o2[20] = 0; i2[21, 0] = 3e38; o2[22, 2] = 3e38; o2[23, 1] = -np.inf
+        for thr in (1.0, 5.0, 1e-3):
+            ref = _pnp_ref(oracle_mod, mods, K, o2, i2, thr)
+            cnt = ops.score_pnp(_d(mods, dev), _d(o2, dev), _d(i2, dev), K, thr).cpu().numpy()
+            assert np.array_equal(cnt, ref), (scale, poison, thr, np.nonzero(cnt != ref)[0][:10])
+            seen = max(seen, int(ref.max()))
+            if scale == 1.0 and not poison and thr == 1.0:
+                assert ref[z0] >= 15                              # the z == 0 pose really has inliers (z := 1 branch)
+    assert seen > 100
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_score_pnp_fuzz(oracle_mod, dev, seed):
+    """random scenes, scene scales, intrinsics, pose perturbations and thresholds (0.01 px to 30 px): counts equal
+    the scalar definition whatever tier decides."""
+    rng = np.random.default_rng(300 + seed)
+    n = int(rng.integers(33, 2500))
+    K = [synth.K_MALAGA, synth.K_KITTI, synth.K_PARKING][seed % 3]
+    size = [synth.IMAGE_SIZE["malaga"], synth.IMAGE_SIZE["kitti"], synth.IMAGE_SIZE["parking"]][seed % 3]
+    ps = synth.pnp_scene(n, K=K, size=size, seed=400 + seed, outlier_frac=float(rng.uniform(0, 0.6)), noise_px=float(rng.uniform(0, 2)))
+    scale = float(10 ** rng.uniform(-2, 2))                     # metres -> other units: t scales with the points
+    obj = (ps["obj"].astype(np.float64) * scale).astype(np.float32); img = ps["img"]
+    pm = _pnp_models(oracle_mod, obj, img, K, 120)
+    jit = pm * (1 + rng.normal(0, 1e-3, pm.shape))              # slightly non-orthogonal, slightly wrong poses
+    true = np.concatenate([ps["R"].reshape(9), ps["t"] * scale])[None]
+    models = np.concatenate([pm, jit, true])
+    best = 0
+    for thr in list(10 ** rng.uniform(-2, 1.5, 4)) + [8.0]:
+        cnt = ops.score_pnp(_d(models, dev), _d(obj, dev), _d(img, dev), K, float(thr)).cpu().numpy()
+        ref = _pnp_ref(oracle_mod, models, K, obj, img, float(thr))
+        assert np.array_equal(cnt, ref), (seed, thr, np.nonzero(cnt != ref)[0][:5])
+        best = max(best, int(ref[-1]))
+    assert best > 0.2 * n                                       # the true pose collects the scene's inliers at 8 px
+
+
 def test_score_and_mask_ess(oracle_mod, dev):
     sc = synth.two_view_scene(3000, seed=11)
     p1, p2, K = sc["p1"], sc["p2"], sc["K"]

@@ -255,6 +255,98 @@ __device__ __forceinline__ float pnp_err(const double* M, double fx, double fy, 
     return s;
 }
 
+// Sure-inlier / sure-outlier filter for pnp_err in f32, sign-bit form like fund_filter32_signs (the exact path
+// costs ~180 issue cycles per correspondence on gfx950: 20 f64 operations, a correctly rounded f64 divide and two
+// v_cvt_f32_f64 at 20 cycles each; this costs ~55).  With the rows of [R|t] scaled by fx, fy, 1 and by a common
+// power of two (max entry in [0.5,1)), u = (iu - cx, iv - cy) and
+//   e = z u - (x'', y'')     (x'' = fx x, y'' = fy y, z the three row products)
+// the reprojection error is |e| / |z| in pixels, so "error <= T" is "|e|^2 <= T^2 z^2" -- no divide.  Budget
+// (u = 2^-24; Sxy, Sz bound every partial sum of the pixel rows' and of the depth row's products over the staged
+// chunk; Um, Im bound |u| and |(iu,iv)| over the chunk, all >= 1):
+//   * f32 evaluation: x'', y'' within 2^-21 Sxy and z within zeta = 2^-21 Sz of their real values (entry rounding
+//     + 3 FMAs: 2^-22 S, 2x slack), each component of e within a = 2^-20 (Sz Um + Sxy);
+//   * the exact path against real arithmetic: as long as |z| >= 2^-10 Sz (no cancellation beyond 10 bits) its f64
+//     noise is <= 2^-40 (Um + Im + 1 + err) + 2^-41 Sxy/Sz px, and the f32 rounding of the projected pixel and of
+//     the f32 difference, squares and sum move sqrt(s) by <= 2^-20 err + 2 g0 with
+//     g0 = 2^-23 (Im + Um + 2) + 2^-38 Sxy/Sz px;
+//   * (|e| + sqrt2 a)^2 <= (1+rho) e^2 + 2 a^2 (1+1/rho) and (|z| - zeta)^2 >= (1-rho) z^2 - zeta^2 / rho
+//     (AM-GM, rho = 2^-8), and the mirror images for the outlier side.
+// Hence, with T = sqrt(thr2), T_lo = (T - 2 g0)(1 - 2^-20), T_hi = (T + 2 g0)/(1 - 2^-20), kappa = 2^-19 Sz^2:
+//   sure inlier   <=  e2 + C < tlo (z2 - kappa)      tlo = T_lo^2 (1-rho)/(1+rho) (1 - 2^-20)
+//   sure outlier  <=  e2 - C > thi z2  and  z2 > kappa   thi = T_hi^2 (1+rho)/(1-rho) (1 + 2^-20)
+// (C collects the constant terms of both sides; z2 > kappa keeps the exact path's 1/z away from the z == 0
+// special case and from cancellation).  Same domain rules as fund_filter32_signs: tame chunk, usable model,
+// thr2 in [2^-40, 2^40]; everything else, and every "cannot tell", takes pnp_err.
+struct PnpFilter32 {
+    float R[12];                 // rows (fx r0 | fx t0), (fy r1 | fy t1), (r2 | t2), scaled, as R[0..2] t R[3] ...
+    float tlo, thi, c, kappa;    // c already holds tlo * kappa for the inlier side
+    bool usable;
+};
+
+__device__ __forceinline__ PnpFilter32 pnp_filter32_setup(const double* M, double fx, double fy, float thr2, double Pm,
+                                                          double Um, double Im)
+{
+    PnpFilter32 f;
+    double A[12];
+    A[0] = fx * M[0]; A[1] = fx * M[1]; A[2] = fx * M[2]; A[3] = fx * M[9];
+    A[4] = fy * M[3]; A[5] = fy * M[4]; A[6] = fy * M[5]; A[7] = fy * M[10];
+    A[8] = M[6]; A[9] = M[7]; A[10] = M[8]; A[11] = M[11];
+    double fm = 0., nanprobe = 0.;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { fm = fmax(fm, fabs(A[k])); nanprobe += A[k] * 0.; }
+    f.usable = fm > 0x1p-300 && fm < 0x1p300 && nanprobe == 0. && thr2 >= 0x1p-40f && thr2 <= 0x1p40f;
+    int e = 0;
+    (void)frexp(f.usable ? fm : 1., &e);
+    const double sigma = ldexp(1., -e);
+    double Srow[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double row = 0.;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double g = A[4 * r + k] * sigma;
+            f.R[4 * r + k] = (float)g;
+            row += fabs(g) * (k < 3 ? Pm : 1.);
+        }
+        Srow[r] = row;
+    }
+    const double Sxy = fmax(Srow[0], Srow[1]), Sz = Srow[2];
+    // a depth row that is (nearly) all zero against the pixel rows: 1/z amplifies the exact path's f64 noise beyond
+    // what g0 budgets -- leave such poses to the exact path altogether
+    f.usable = f.usable && Sz > 0. && Sxy <= 0x1p30 * Sz;
+    const double rho = 0x1p-8, T = sqrt((double)thr2);
+    const double g0 = 0x1p-23 * (Im + Um + 2.) + (f.usable ? 0x1p-38 * (Sxy / Sz) : 0.);
+    const double Tlo = (T - 2. * g0) * (1. - 0x1p-20), Thi = (T + 2. * g0) / (1. - 0x1p-20);
+    const double zeta = 0x1p-21 * Sz, a = 0x1p-20 * (Sz * Um + Sxy), kappa = 0x1p-19 * Sz * Sz;
+    const double tlo = Tlo > 0. ? Tlo * Tlo * (1. - rho) / (1. + rho) * (1. - 0x1p-20) : -1.;     // -1: never sure inlier
+    const double thi = Thi * Thi * (1. + rho) / (1. - rho) * (1. + 0x1p-20);
+    const double c_in = (2. * a * a * (1. + 1. / rho) + Tlo * Tlo * zeta * zeta / rho) / (1. + rho) + fmax(tlo, 0.) * kappa;
+    const double c_out = (2. * a * a / rho + Thi * Thi * zeta * zeta * (1. + 1. / rho)) / (1. - rho);
+    f.tlo = (float)tlo;
+    f.thi = (float)(thi * (1. + 0x1p-22));
+    f.c = (float)(fmax(c_in, c_out) * (1. + 0x1p-20));
+    f.kappa = (float)(kappa * (1. + 0x1p-22));
+    return f;
+}
+
+__device__ __forceinline__ void pnp_filter32_signs(const PnpFilter32& f, float X, float Y, float Z, float ux, float uy,
+                                                   uint32_t& in_bits, uint32_t& out_bits)
+{
+    const float* R = f.R;
+    const float x = __builtin_fmaf(R[0], X, __builtin_fmaf(R[1], Y, __builtin_fmaf(R[2], Z, R[3])));
+    const float y = __builtin_fmaf(R[4], X, __builtin_fmaf(R[5], Y, __builtin_fmaf(R[6], Z, R[7])));
+    const float z = __builtin_fmaf(R[8], X, __builtin_fmaf(R[9], Y, __builtin_fmaf(R[10], Z, R[11])));
+    const float ex = __builtin_fmaf(z, ux, -x), ey = __builtin_fmaf(z, uy, -y);
+    const float e2 = __builtin_fmaf(ex, ex, ey * ey);
+    const float z2 = z * z;
+    const float lo = e2 + f.c, nhi = f.c - e2;
+    const float r_in = __builtin_fmaf(-f.tlo, z2, lo);             // < 0: sure inlier (implies z2 > kappa)
+    const float r_out = __builtin_fmaf(f.thi, z2, nhi);            // < 0: outlier by more than the budget ...
+    const float g = f.kappa - z2;                                  // ... counted only where z2 > kappa
+    in_bits = __builtin_amdgcn_alignbit(in_bits, __float_as_uint(r_in), 31);
+    out_bits = __builtin_amdgcn_alignbit(out_bits, __float_as_uint(fmaxf(r_out, g)), 31);
+}
+
 // counts[b][slot] = 0 where a model exists (valid byte, or slot%slots_per_sample < nmodels), else -1
 __global__ void init_counts_kernel(const uint8_t* __restrict__ valid, const int32_t* __restrict__ nmodels,
                                    int slots_per_sample, int total, int32_t* __restrict__ counts)
@@ -299,7 +391,7 @@ void score_kernel(const ScoreArgs a)
     if (p0 >= n || (int)(blockIdx.x * kThreads) >= nslots) return;      // block-uniform
     const int np = min(a.chunk, n - p0);
 
-    __shared__ double sscale[3][kThreads / 64];
+    __shared__ double sscale[4][kThreads / 64];
     if (KIND == kFund) {
         const float4* pts = (const float4*)a.pts + (size_t)b * a.N + p0;
         double p1 = 1., p2 = 1.;                   // chunk-wide bounds on max(|x|,|y|,1) of either image
@@ -325,11 +417,32 @@ void score_kernel(const ScoreArgs a)
         const double* pts = (const double*)a.pts + ((size_t)b * a.N + p0) * 4;
         for (int i = threadIdx.x; i < np * 4; i += kThreads) sp[i] = pts[i];
     } else {
+        // 32 B per correspondence, all f32 (the object points are f32 to begin with): (X Y Z ux) (uy iu iv -), with
+        // u = (float)(iu - cx), (float)(iv - cy) for the filter tier; plus the chunk-wide bounds the filter needs
         const float* obj = (const float*)a.pts + ((size_t)b * a.N + p0) * 3;
         const float2* img = a.img + (size_t)b * a.N + p0;
+        float4* spf = (float4*)sp;
+        float pm = 1.f, um = 1.f, im = 1.f;
+        bool tame = true;
         for (int i = threadIdx.x; i < np; i += kThreads) {
-            sp[4 * i] = obj[3 * i]; sp[4 * i + 1] = obj[3 * i + 1]; sp[4 * i + 2] = obj[3 * i + 2];
-            *(float2*)(sp + 4 * i + 3) = img[i];
+            const float X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
+            const float2 uv = img[i];
+            const float ux = (float)((double)uv.x - a.cx), uy = (float)((double)uv.y - a.cy);
+            spf[2 * i] = make_float4(X, Y, Z, ux);
+            spf[2 * i + 1] = make_float4(uy, uv.x, uv.y, 0.f);
+            pm = fmaxf(pm, fmaxf(fabsf(X), fmaxf(fabsf(Y), fabsf(Z))));
+            um = fmaxf(um, fmaxf(fabsf(ux), fabsf(uy)));
+            im = fmaxf(im, fmaxf(fabsf(uv.x), fabsf(uv.y)));
+            tame = tame && fabsf(X) <= 0x1p20f && fabsf(Y) <= 0x1p20f && fabsf(Z) <= 0x1p20f && fabsf(uv.x) <= 0x1p20f &&
+                   fabsf(uv.y) <= 0x1p20f && fabsf(ux) <= 0x1p20f && fabsf(uy) <= 0x1p20f;
+        }
+        for (int o = 32; o; o >>= 1) {
+            pm = fmaxf(pm, __shfl_xor(pm, o)); um = fmaxf(um, __shfl_xor(um, o)); im = fmaxf(im, __shfl_xor(im, o));
+        }
+        tame = __all(tame);
+        if ((threadIdx.x & 63) == 0) {
+            sscale[0][threadIdx.x >> 6] = pm; sscale[1][threadIdx.x >> 6] = um; sscale[2][threadIdx.x >> 6] = tame ? 1. : 0.;
+            sscale[3][threadIdx.x >> 6] = im;
         }
     }
 
@@ -415,17 +528,50 @@ void score_kernel(const ScoreArgs a)
                 }
             }
         }
+    } else if (KIND == kPnp) {
+        double pm = sscale[0][0], um = sscale[1][0], tame_chunk = sscale[2][0], im = sscale[3][0];
+#pragma unroll
+        for (int w = 1; w < kThreads / 64; ++w) {
+            pm = fmax(pm, sscale[0][w]); um = fmax(um, sscale[1][w]); im = fmax(im, sscale[3][w]);
+            tame_chunk = fmin(tame_chunk, sscale[2][w]);
+        }
+        const float4* spf = (const float4*)sp;
+        auto exact = [&](int i) -> int {
+            const float4 p = spf[2 * i], q = spf[2 * i + 1];
+            return pnp_err(M, a.fx, a.fy, a.cx, a.cy, p.x, p.y, p.z, q.y, q.z) <= a.thr2;
+        };
+        const PnpFilter32 pf = pnp_filter32_setup(M, a.fx, a.fy, a.thr2, pm, um, im);
+        const bool fast = tame_chunk != 0.;                                         // workgroup-uniform
+        const uint32_t force = pf.usable ? 0u : 0xffffffffu;
+        int i0 = 0;
+        if (fast) {
+            for (; i0 + 32 <= np; i0 += 32) {
+                uint32_t in_bits = 0, out_bits = 0;
+#pragma unroll 4
+                for (int k = 0; k < 32; ++k) {
+                    const float4 p = spf[2 * (i0 + k)];
+                    const float uy = ((const float*)sp)[8 * (i0 + k) + 4];
+                    pnp_filter32_signs(pf, p.x, p.y, p.z, p.w, uy, in_bits, out_bits);
+                }
+                uint32_t bits = ~(in_bits | out_bits) | force;
+                cnt += __popc(in_bits & ~force);
+                if (!live) bits = 0;
+                // tier 2: the exact evaluation for what the filter could not decide, one entry per lane per trip
+                while (__any(bits != 0)) {
+                    if (bits) {
+                        const int pos = 31 - __clz(bits);
+                        bits &= ~(1u << pos);
+                        cnt += exact(i0 + 31 - pos);
+                    }
+                }
+            }
+        }
+        for (; i0 < np; ++i0) cnt += exact(i0);
     } else {
         auto one = [&](int i) {
             const double2 u = *(const double2*)(sp + 4 * i);
-            if (KIND == kPnp) {
-                const double Z = sp[4 * i + 2];
-                const float2 uv = *(const float2*)(sp + 4 * i + 3);
-                cnt += pnp_err(M, a.fx, a.fy, a.cx, a.cy, u.x, u.y, Z, uv.x, uv.y) <= a.thr2;
-            } else {
-                const double2 v = *(const double2*)(sp + 4 * i + 2);
-                cnt += sampson_err(M, u.x, u.y, v.x, v.y) <= a.thr2;
-            }
+            const double2 v = *(const double2*)(sp + 4 * i + 2);
+            cnt += sampson_err(M, u.x, u.y, v.x, v.y) <= a.thr2;
         };
         // four correspondences per trip: the loop bookkeeping (and the LDS wait) is paid once per four
         // error evaluations; each evaluation itself is unchanged
