@@ -14,8 +14,9 @@
  *   - return value: 0 = VO_OK, negative = VO_E* below; vo_last_error() gives the text;
  *   - scratch memory comes in through an explicit workspace argument whose size the
  *     matching *_workspace_bytes() call reports;
- *   - thread-safe for distinct streams; the only global state is the per-thread
- *     last-error string.
+ *   - thread-safe for distinct streams.  Global state: the per-thread last-error string; the process-wide
+ *     record list of the measurement aid vo_profile_* (off by default, not thread-safe); and, per GPU,
+ *     the fixed scratch array of vo_ransac_batch_static (calls on one GPU share it).
  */
 #ifndef VO_HIP_H
 #define VO_HIP_H
@@ -295,6 +296,11 @@ int vo_argmax_first(const int32_t* counts, int n, int32_t* result, void* stream)
  * ---------------------------------------------------------------------------------- */
 int vo_host_gen_subsets(int n_points, int model_points, int max_iters,
                         const float* pts4_host, int32_t* subsets_host);
+/* The same with getSubset's maxAttempts spelled out: RANSACPointSetRegistrator::run passes 10000 (what
+ * vo_host_gen_subsets uses), LMeDSPointSetRegistrator::run -- cv2.findFundamentalMat with 8..14 points -- leaves
+ * the default of 1000. */
+int vo_host_gen_subsets_attempts(int n_points, int model_points, int max_iters, int max_attempts,
+                                 const float* pts4_host, int32_t* subsets_host);
 int vo_host_update_num_iters(double p, double ep, int model_points, int max_iters);
 
 /* Host-only: the EPnP refit cv.solvePnPRansac(flags=SOLVEPNP_P3P) applies to the inliers of the

@@ -41,6 +41,8 @@ def _sig(lib):
     lib.vo_or_rng_stream.argtypes = [C.c_uint64, C.c_int, _c_u32p]
     lib.vo_or_gen_subsets.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, _c_i32p]
     lib.vo_or_gen_subsets.restype = C.c_int
+    lib.vo_or_gen_subsets_attempts.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, _c_i32p, C.c_int]
+    lib.vo_or_gen_subsets_attempts.restype = C.c_int
     lib.vo_or_update_num_iters.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
     lib.vo_or_update_num_iters.restype = C.c_int
     lib.vo_or_ransac_replay.argtypes = [_c_i32p, _c_i32p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -111,12 +111,13 @@ int vo_or_fund_check_subset(const float* ms1, const float* ms2, int count)
     return !have_collinear(ms1, count) && !have_collinear(ms2, count);
 }
 
-/* one getSubset(..., maxAttempts=10000) call; returns 1 if a subset was accepted */
+/* one getSubset(..., maxAttempts) call; returns 1 if a subset was accepted.  RANSACPointSetRegistrator::run passes
+ * 10000, LMeDSPointSetRegistrator::run leaves the declaration's default of 1000 (ptsetreg.cpp, 4.6.0) */
 static int get_subset(or_rng* rng, int count, int mp, int check_mode,
-                      const float* m1, const float* m2, int32_t* idx)
+                      const float* m1, const float* m2, int32_t* idx, int max_attempts)
 {
     float s1[2 * 16], s2[2 * 16];
-    for (int attempt = 0; attempt < 10000; ++attempt) {
+    for (int attempt = 0; attempt < max_attempts; ++attempt) {
         for (int i = 0; i < mp; ++i) {
             int v;
             for (;;) {
@@ -139,13 +140,19 @@ static int get_subset(or_rng* rng, int count, int mp, int check_mode,
 int vo_or_gen_subsets(int count, int model_points, int max_iters, int check_mode,
                       const float* m1, const float* m2, int32_t* subsets)
 {
+    return vo_or_gen_subsets_attempts(count, model_points, max_iters, check_mode, m1, m2, subsets, 10000);
+}
+
+int vo_or_gen_subsets_attempts(int count, int model_points, int max_iters, int check_mode,
+                               const float* m1, const float* m2, int32_t* subsets, int max_attempts)
+{
     if (count < model_points || model_points > 16) return 0;
     or_rng rng; rng_init(&rng, (uint64_t)-1);
     int niters = max_iters > 1 ? max_iters : 1;
     int it = 0;
     for (; it < niters; ++it)
         if (!get_subset(&rng, count, model_points, check_mode, m1, m2,
-                        subsets + (size_t)it * model_points))
+                        subsets + (size_t)it * model_points, max_attempts))
             break;
     return it;
 }

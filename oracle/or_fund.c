@@ -211,7 +211,7 @@ int vo_or_find_fundamental_lmeds(const float* m1, const float* m2, int n, double
     float* err = (float*)malloc(sizeof(float) * n);
     int32_t* key = (int32_t*)malloc(sizeof(int32_t) * n);
     int32_t* subsets = (int32_t*)malloc(sizeof(int32_t) * mp * (size_t)niters);
-    int n_gen = vo_or_gen_subsets(n, mp, niters, 1, m1, m2, subsets);
+    int n_gen = vo_or_gen_subsets_attempts(n, mp, niters, 1, m1, m2, subsets, 1000);   /* LMedS: getSubset's default maxAttempts */
     double min_median = DBL_MAX;
     int result = 0;
     for (int iter = 0; iter < niters && iter < n_gen; ++iter) {

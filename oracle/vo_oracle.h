@@ -48,6 +48,8 @@ void vo_or_rng_stream(uint64_t seed, int n, uint32_t* out);
 /* check_mode 0: none; 1: fundamental-matrix collinearity test on m1,m2 (N x 2 f32).
  * Generates subsets for iterations 0..max_iters-1 from RNG((uint64)-1); stops at the
  * first iteration whose 10000 attempts all fail.  Returns #iterations generated. */
+int vo_or_gen_subsets_attempts(int count, int model_points, int max_iters, int check_mode,
+                               const float* m1, const float* m2, int32_t* subsets, int max_attempts);
 int vo_or_gen_subsets(int count, int model_points, int max_iters, int check_mode,
                       const float* m1, const float* m2, int32_t* subsets);
 int vo_or_update_num_iters(double p, double ep, int model_points, int max_iters);

@@ -330,3 +330,23 @@ def test_oracle_lmeds_small_point_sets(oracle_mod):
     sc = synth.two_view_scene(15, seed=5, noise_px=0.0, outlier_frac=0.0)
     F, mask, info = oracle_mod.find_fundamental_mat(sc["p1"], sc["p2"], 1.0, 0.99, 500)
     assert F is not None and info[3] < 500
+
+
+def test_gen_subsets_attempt_limits_equal_oracle(oracle_mod):
+    """getSubset's maxAttempts: 10000 in the RANSAC registrator, 1000 in the LMedS one (8..14 points).  Host helper of
+    the library against the oracle on point sets whose last-point collinearity check rejects most or all samples."""
+    import ctypes as C
+    from visual_odometry_amd import ops
+    rng = np.random.default_rng(3)
+    lib = oracle_mod.lib()
+    for n, frac_line in ((12, 1.0), (12, 0.75), (40, 0.9), (10, 0.0)):
+        p = rng.uniform(0, 500, (n, 4)).astype(np.float32)
+        k = int(frac_line * n)
+        p[:k, 1] = 2.0 * p[:k, 0] + 1.0                    # first image: k points on one line
+        for attempts in (1000, 10000, 3):
+            got = ops.gen_subsets(n, 7, 60, p, max_attempts=attempts)
+            exp = np.zeros((60, 7), np.int32)
+            a, b = np.ascontiguousarray(p[:, :2]), np.ascontiguousarray(p[:, 2:])
+            m = lib.vo_or_gen_subsets_attempts(n, 7, 60, 1, a.ctypes.data, b.ctypes.data, exp, attempts)
+            assert len(got) == m and np.array_equal(got, exp[:m]), (n, frac_line, attempts)
+    assert len(ops.gen_subsets(12, 7, 60, np.tile(np.arange(12, dtype=np.float32)[:, None], (1, 4)))) == 0

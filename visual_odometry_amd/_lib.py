@@ -64,6 +64,7 @@ _SIGNATURES = {
     "vo_ransac_batch_static": (_i, [_i, _vp, _i, _vp, _vp, C.POINTER(_d), _i, _vp, _i, _f, _d, _i, _i, _vp, _vp, _vp, _vp,
                                     _vp]),
     "vo_host_gen_subsets": (_i, [_i, _i, _i, _vp, _vp]),
+    "vo_host_gen_subsets_attempts": (_i, [_i, _i, _i, _i, _vp, _vp]),
     "vo_host_update_num_iters": (_i, [_d, _d, _i, _i]),
     "vo_host_epnp": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "vo_profile_enable": (_i, [_i, _i]),

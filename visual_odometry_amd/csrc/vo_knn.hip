@@ -7,16 +7,17 @@
 // order of key = 2 q.t - |t|^2, so each lane maximises key; q.t comes out of
 // v_mfma_i32_32x32x32_i8 exactly (int32 accumulate), and D is rebuilt at the very end.
 //
-// Data movement: a workgroup (4 waves) owns 256 query rows and one split of the train rows.
-// Every wave keeps its 64 query rows as MFMA B fragments in registers for the whole sweep
-// (queries sit on the MFMA column = lane axis, so a lane's running top-2 never leaves the
-// lane).  Train rows stream through LDS in 128-row chunks (double buffered, 16-byte slots
-// XOR-swizzled so the ds_read_b128 of an A fragment is bank-conflict free) and are shared
-// by the four waves.  Per 32x32 output tile the VALU does 3 ops per element:
+// Data movement: a workgroup (8 waves) owns 512 query rows (2 sets of 32 per wave) and one split of the train
+// rows.  Every wave keeps its query rows as MFMA B fragments in registers for the whole sweep (queries sit on
+// the MFMA column = lane axis, so a lane's running top-2 never leaves the lane).  Train rows stream through LDS
+// in 128-row chunks (LDS-DMA, double buffered, 16-byte slots XOR-swizzled on the source side so that the
+// ds_read_b128 of an A fragment is bank-conflict free) and are shared by the eight waves.  Per 32x32 output tile
+// the VALU does 2.5 ops per element: the packed key
 //     p  = (dot << 9) + c[row]        c[row] = (-|t|^2 << 8) | (15-tile)<<4 | (15-slot)
-//     m2 = med3(m1, m2, p) ; m1 = max(m1, p)
-// The low 8 bits make p unique inside a 16-tile segment and order equal keys by ascending
-// train index, which is OpenCV's tie rule (strict '<' insertion while scanning upwards).
+// and, two keys at a time, m1 = max3(m1, p0, p1), m2 = max(m2, med3(m1, p0, p1)).
+// The low 8 bits make p unique inside a 16-tile segment and order equal keys by ascending train index, which
+// is OpenCV's tie rule (strict '<' insertion while scanning upwards).  Workgroups of one problem are pinned to
+// one XCD (VO_KNN_XCD) so that its train rows are fetched into one L2 only.
 #include "vo_common.h"
 #include <limits.h>
 #include <stdlib.h>

@@ -473,6 +473,13 @@ extern "C" int vo_argmax_first(const int32_t* counts, int n, int32_t* result, vo
 extern "C" int vo_host_gen_subsets(int n_points, int model_points, int max_iters, const float* pts4_host,
                                    int32_t* subsets_host)
 {
+    return vo_host_gen_subsets_attempts(n_points, model_points, max_iters, 10000, pts4_host, subsets_host);
+}
+
+extern "C" int vo_host_gen_subsets_attempts(int n_points, int model_points, int max_iters, int max_attempts,
+                                            const float* pts4_host, int32_t* subsets_host)
+{
+    VO_CHECK_ARG(max_attempts >= 1, VO_EINVAL, "vo_host_gen_subsets_attempts: max_attempts must be positive");
     VO_CHECK_ARG(model_points >= 1 && model_points <= 16, VO_EINVAL, "vo_host_gen_subsets: model_points out of range");
     VO_CHECK_ARG(subsets_host != nullptr, VO_EINVAL, "vo_host_gen_subsets: null output");
     if (n_points < model_points) return 0;
@@ -482,7 +489,7 @@ extern "C" int vo_host_gen_subsets(int n_points, int model_points, int max_iters
     for (; it < niters; ++it) {
         int32_t* idx = subsets_host + (size_t)it * model_points;
         bool found = false;
-        for (int attempt = 0; attempt < 10000 && !found; ++attempt) {
+        for (int attempt = 0; attempt < max_attempts && !found; ++attempt) {
             for (int i = 0; i < model_points; ++i) {
                 int v;
                 for (;;) {

@@ -4,16 +4,18 @@
 // cv.solvePnPRansac (reference src/utils/geometry.py:39,44 and src/pnp.py:16-26; semantics:
 // SURVEY.md Appendix A.2-A.6, Appendix B for the exactness rules).
 //
-// Exactness: every value that reaches the threshold compare is produced by the same IEEE
-// f64/f32 operations in the same order as the scalar definition (this file is compiled with
-// -ffp-contract=off; f64 divide and f32->f64->f32 conversions are correctly rounded on
-// gfx950), so counts and masks are bit-for-bit those of a CPU evaluation.
+// Exactness: counts and masks are bit for bit those of the scalar definitions below (fund_err, sampson_err,
+// pnp_err: the same IEEE f64/f32 operations in the same order as a CPU evaluation; this file is compiled with
+// -ffp-contract=off; f64 divide and f32<->f64 conversions are correctly rounded on gfx950).  The COUNT kernels
+// for F and PnP do not evaluate those definitions for every correspondence: a division-free f32 filter with
+// rigorous error bounds settles every verdict that is not within rounding distance of the threshold ("sure
+// inlier" / "sure outlier", left in sign bits), and only the rest takes the f64 filter (F) and the exact
+// evaluation.  The mask kernels always run the exact definitions.
 //
-// Mapping: one thread owns one model (9 or 12 doubles in VGPRs); a workgroup of 256 models
-// walks a chunk of correspondences that it first converts to f64 in LDS, so the inner loop
-// reads every operand with wave-uniform (broadcast) ds_read_b128 and is pure f64 VALU.  The
-// grid is (model blocks) x (point chunks); chunk sums meet in counts[] through integer
-// atomics, which are order-independent.
+// Mapping: one thread owns one model (registers); a workgroup of 256 models walks a chunk of <= 512
+// correspondences staged in LDS (f32 for F and PnP, f64 for E), so the inner loop reads every operand with
+// wave-uniform (broadcast) ds_read and is pure VALU.  The grid is (model blocks) x (point chunks) x (problems);
+// chunk sums meet in counts[] through integer atomics, which are order-independent.
 #include "vo_common.h"
 
 #ifndef VO_SCORE_G

@@ -445,16 +445,18 @@ def gen_subsets_device(n_dev: Optional[torch.Tensor], N: int, model_points: int,
 
 
 # ------------------------------------------------------------------------------- host helpers
-def gen_subsets(n_points: int, model_points: int, max_iters: int, pts4_host: Optional[np.ndarray] = None) -> np.ndarray:
-    """cv::RNG((uint64)-1) + getSubset sample stream (host only). (n_generated, model_points) i32."""
+def gen_subsets(n_points: int, model_points: int, max_iters: int, pts4_host: Optional[np.ndarray] = None,
+                max_attempts: int = 10000) -> np.ndarray:
+    """cv::RNG((uint64)-1) + getSubset sample stream (host only). (n_generated, model_points) i32.
+    max_attempts: 10000 in OpenCV's RANSAC registrator, 1000 (getSubset's default) in its LMedS registrator."""
     lib = _lib.load()
     out = np.zeros((max(int(max_iters), 1), model_points), dtype=np.int32)
     p = None
     if pts4_host is not None:
         pts4_host = np.ascontiguousarray(pts4_host, dtype=np.float32).reshape(-1, 4)
         p = pts4_host.ctypes.data
-    n = lib.vo_host_gen_subsets(int(n_points), int(model_points), int(max_iters), p, out.ctypes.data)
-    _lib.check(n, "vo_host_gen_subsets")
+    n = lib.vo_host_gen_subsets_attempts(int(n_points), int(model_points), int(max_iters), int(max_attempts), p, out.ctypes.data)
+    _lib.check(n, "vo_host_gen_subsets_attempts")
     return out[:n]
 
 

@@ -63,6 +63,7 @@ class PairBatchResult:
 
 
 _side = {}
+_SIDE_MAX = 16
 
 
 def _side_stream(dev: torch.device, main: "torch.cuda.Stream") -> "torch.cuda.Stream":
@@ -70,10 +71,14 @@ def _side_stream(dev: torch.device, main: "torch.cuda.Stream") -> "torch.cuda.St
     batches concurrently on streams of their own do not serialise their PnP chains on one."""
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), main.cuda_stream)
     if key not in _side:
+        while len(_side) >= _SIDE_MAX:                 # callers that keep creating streams: drop the oldest entry
+            _side.pop(next(iter(_side)))
         # default priority on purpose: a high-priority stream changed nothing in the measured overlap, and
         # with an RCCL communicator alive in the process (bench.py under torch.distributed.run) the
         # cross-stream waits of the chain never completed on it (DESIGN.md section 5)
-        _side[key] = torch.cuda.Stream(device=dev)
+        import os
+        prio = int(os.environ.get("VO_SIDE_PRIORITY", "0"))      # diagnostic knob only (scripts/diag/dist_hang.py, DESIGN.md 5)
+        _side[key] = torch.cuda.Stream(device=dev, priority=prio)
     return _side[key]
 
 

@@ -54,7 +54,7 @@ def _find_fundamental_lmeds(pts4: np.ndarray, confidence: float, max_iters: int,
     niters = max(ops.update_num_iters(confidence, 0.45, 7, max_iters), 3)
     info.niters = niters
     mask0 = np.zeros((n, 1), np.uint8)
-    subsets = ops.gen_subsets(n, 7, niters, pts4)
+    subsets = ops.gen_subsets(n, 7, niters, pts4, max_attempts=1000)      # LMedS: getSubset's default maxAttempts
     info.n_generated = len(subsets)
     if len(subsets) == 0:
         return None, mask0, info
