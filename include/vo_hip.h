@@ -167,6 +167,22 @@ int vo_ransac_batch(int kind, const int32_t* samples, int H, const void* pts, co
                     double* best_model, double* best_rvec, uint8_t* mask, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* The small-input branches of cv2.findFundamentalMat(..., cv2.RANSAC, ...) (reference src/utils/geometry.py:39 with
+ * few matches) for a whole batch of frame pairs, on the device: pairs with 8..14 correspondences get
+ * OpenCV's LMedS registrator (getSubset with its default 1000 attempts, 7-point models ranked by the median of
+ * their errors, the first strictly smallest wins, inliers within 2.5 * 1.4826 * (1 + 5/(n-7)) * sqrt(median), at
+ * least 7 of them or no model), pairs with exactly 7 get every solution of the seven points as they stand
+ * (models7 batch x 3 x 9, nmodels7 batch; F = the first solution, mask all ones -- cv2 returns the solutions
+ * stacked as a 3k x 3 matrix).  Rows of result / F / mask of pairs with other counts are left untouched, so the
+ * outputs of vo_ransac_batch(kind 0) can be passed in directly.  n_match: batch x int32 true correspondence counts;
+ * pts4 batch x N x 4 f32.  The number of LMedS iterations follows from confidence and max_iters
+ * (vo_fund_small_iterations); result rows hold it as their fourth entry. */
+int vo_fund_small_iterations(double confidence, int max_iters);
+size_t vo_fund_small_workspace_bytes(double confidence, int max_iters, int batch);
+int vo_fund_small_batch(const float* pts4, int N, const int32_t* n_match, int batch, double confidence, int max_iters,
+                        int32_t* result, double* F, uint8_t* mask, double* models7, int32_t* nmodels7,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* One vo_ransac_batch over several GPUs (the hypothesis range of every problem is split over
  * the ranks, correspondences are replicated).  No counterpart in the reference, which is single-process;
  * the three calls reproduce vo_ransac_batch(first_block = 0) bit for bit:

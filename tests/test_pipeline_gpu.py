@@ -156,17 +156,20 @@ def test_deferred_pnp_wait_gives_the_same_results(dev):
             assert np.array_equal(getattr(r, k).cpu().numpy(), v), k
 
 
-def test_finish_small_pairs_runs_lmeds(det_math, dev):
-    """Pairs with 8..14 matches: the fused batch leaves them without an F model, finish_small_pairs gives them
-    what cv2.findFundamentalMat's LMedS branch gives (the oracle's restatement of it), other pairs untouched."""
+def test_small_pairs_inside_the_batch(det_math, dev):
+    """Pairs with 7..14 matches inside the fused batch get what cv2.findFundamentalMat's small-input branches give
+    (the oracle's restatement, and the single-pair entry point): LMedS for 8..14 matches, every 7-point solution
+    for exactly 7; pairs with fewer than 7 get no model, large pairs are untouched."""
+    from visual_odometry_amd import ransac
     o = det_math
-    nq, nt = 12, 60
+    nq, nt = 14, 60
     rng = np.random.default_rng(5)
+    want = [12, 9, 5, 7, 14, 8, 7, 13]
     pairs = []
-    for b in range(3):
-        sc = synth.two_view_scene(nq, K=synth.K_MALAGA, size=synth.IMAGE_SIZE["malaga"], seed=4000 + b, outlier_frac=0.0)
+    for b, k in enumerate(want):
+        sc = synth.two_view_scene(nq, K=synth.K_MALAGA, size=synth.IMAGE_SIZE["malaga"], seed=4000 + b,
+                                  outlier_frac=0.3 if b in (4, 7) else 0.0)
         q, t = synth.sift_like(nq, rng), synth.sift_like(nt, rng)
-        k = nq if b < 2 else 5                                   # pair 2: only 5 matches -> nothing to do
         dst = rng.permutation(nt)[:k]
         t[dst] = np.clip(np.rint(q[:k] + rng.normal(0, 4.0, (k, 128))), 0, 255)
         kt = rng.uniform(0, 700, (nt, 2)).astype(np.float32)
@@ -175,14 +178,31 @@ def test_finish_small_pairs_runs_lmeds(det_math, dev):
     st = lambda k: _d(np.stack([p[k] for p in pairs]), dev)
     r = pipeline.match_and_ransac(st(0), st(1), st(2), st(3), 0.8, 1.0, 0.99, 200)
     n = r.n_match.cpu().numpy()
-    assert 8 <= n[0] <= 14 and 8 <= n[1] <= 14 and n[2] < 8
-    assert not r.f_mask.any() and (r.f_result[:, 2] == 0).all()   # the fused batch: no model for any of them
-    assert pipeline.finish_small_pairs(r, 1.0, 0.99, 200) == 2
-    for b in range(2):
-        p = r.pts4[b, :n[b]].cpu().numpy()
+    assert list(n) == want
+    assert pipeline.finish_small_pairs(r, 1.0, 0.99, 200) == 7
+    res, F, mask = r.f_result.cpu().numpy(), r.F.cpu().numpy(), r.f_mask.cpu().numpy()
+    f7, n7 = r.f7_models.cpu().numpy(), r.f7_count.cpu().numpy()
+    seen_lmeds = 0
+    for b, k in enumerate(want):
+        p = r.pts4[b, :k].cpu().numpy()
+        assert not mask[b, k:].any()
+        if k < 7:
+            assert not mask[b].any() and res[b, 0] < 0 and n7[b] == 0
+            continue
+        gF, gmask, ginfo = ransac.find_fundamental_ransac(p[:, :2], p[:, 2:], 1.0, 0.99, 200)     # single-pair entry point
+        if k == 7:
+            oF = o.run7point(p[:, :2], p[:, 2:]).reshape(-1, 3)      # the seven points as they stand, all solutions stacked
+            assert n7[b] == oF.shape[0] // 3 and n7[b] >= 1
+            assert np.array_equal(f7[b, :n7[b]].reshape(-1, 3), oF) and np.array_equal(gF, oF)
+            assert np.array_equal(F[b].reshape(3, 3), oF[:3]) and mask[b, :7].all() and res[b, 0] == 0
+            continue
         oF, omask, oinfo = o.find_fundamental_mat(p[:, :2], p[:, 2:], 1.0, 0.99, 200)
-        assert oF is not None
-        assert np.array_equal(r.F[b].cpu().numpy().reshape(3, 3), oF)
-        assert np.array_equal(r.f_mask[b, :n[b]].cpu().numpy(), omask.ravel()) and not r.f_mask[b, n[b]:].any()
-        assert tuple(r.f_result[b].cpu().numpy()) == tuple(int(v) for v in oinfo)
-    assert not r.f_mask[2].any() and int(r.f_result[2, 2]) == 0
+        assert n7[b] == 0
+        assert np.array_equal(mask[b, :k], omask.ravel()) and np.array_equal(gmask, omask)
+        if oF is None:
+            assert res[b, 0] < 0 and not F[b].any() and gF is None
+        else:
+            seen_lmeds += 1
+            assert np.array_equal(F[b].reshape(3, 3), oF) and np.array_equal(gF, oF)
+            assert tuple(res[b]) == tuple(int(v) for v in oinfo)
+    assert seen_lmeds >= 3

@@ -56,6 +56,9 @@ _SIGNATURES = {
     "vo_ransac_workspace_bytes": (_sz, [_i, _i, _i]),
     "vo_ransac_batch": (_i, [_i, _vp, _i, _vp, _vp, C.POINTER(_d), _i, _vp, _i, _f, _d, _i, _i, _vp, _vp, _vp, _vp,
                              _vp, _sz, _vp]),
+    "vo_fund_small_iterations": (_i, [_d, _i]),
+    "vo_fund_small_workspace_bytes": (_sz, [_d, _i, _i]),
+    "vo_fund_small_batch": (_i, [_vp, _i, _vp, _i, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vo_ransac_layout": (_i, [_i, _i, _i, _vp]),
     "vo_ransac_slice_counts": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, C.POINTER(_d), _i, _vp, _i, _f, _vp, _sz, _vp]),
     "vo_ransac_slice_finish": (_i, [_i, _i, _i, _i, _i, _vp, _i, _d, _i, _vp, _sz, _vp, _vp, _vp, _vp]),

@@ -63,6 +63,15 @@ int vo_launch_replay(const int32_t* counts, const int32_t* nmodels, int n_iters,
                      const int32_t* n_dev, int model_points, double confidence, int max_iters, int batch,
                      int32_t* result, hipStream_t s);
 
+int vo_launch_gen_subsets(const int32_t* n_dev, int N, int model_points, int H, const float* pts4, int batch,
+                          int32_t* samples, int32_t* n_generated, int max_attempts, hipStream_t s);
+// frame pairs with 7..14 matches (vo_fund_small_batch): per-problem counts for the two regimes, identity samples for
+// the 7-match case, and the LMedS ranking + result rows
+int vo_launch_small_prepare(const int32_t* n_match, int batch, int H, int32_t* n_lmeds, int32_t* n_small, int32_t* samples,
+                            hipStream_t s);
+int vo_launch_small_finish(const double* models, const int32_t* nmodels, int H, const float* pts4, int N,
+                           const int32_t* n_small, int batch, int32_t* result, double* F, uint8_t* mask, double* models7,
+                           int32_t* nmodels7, hipStream_t s);
 // timing aid (vo_runtime.hip): stage ids for vo_profile_enable's mask
 enum { VO_STAGE_SOLVE = 0, VO_STAGE_SCORE = 1, VO_STAGE_REPLAY = 2, VO_STAGE_MASK = 3, VO_STAGE_KNN = 4 };
 void vo_prof_begin(int stage, int tag, hipStream_t s);

@@ -91,7 +91,7 @@ constexpr int kSubsetThreads = 256;   // speculative samples per round and probl
 
 struct SubsetArgs {
     const int32_t* n_dev; const float4* pts4; int32_t* samples; int32_t* n_generated;
-    int N, model_points, H, check;
+    int N, model_points, H, check, max_attempts;
     unsigned long long jump[kSubsetThreads + 1];      // a^(model_points * l) mod m
 };
 
@@ -147,7 +147,7 @@ void gen_subsets_kernel(const SubsetArgs a)
         int used = 0;
         bool ok = false;
         if (active) {
-            for (int attempt = 0; attempt < 10000 && !ok; ++attempt) {
+            for (int attempt = 0; attempt < a.max_attempts && !ok; ++attempt) {
 #pragma unroll
                 for (int i = 0; i < m; ++i) {
                     int v;
@@ -180,7 +180,7 @@ void gen_subsets_kernel(const SubsetArgs a)
             nact += __popcll(s_act[w]);
         }
         if (first_odd < 0) first_odd = nact - 1;
-        const bool bad = s_fail[first_odd] != 0;          // that thread exhausted its 10000 attempts
+        const bool bad = s_fail[first_odd] != 0;          // that thread exhausted its attempts
         const int nwrite = bad ? first_odd : first_odd + 1;
         if (active && tid < nwrite) {
 #pragma unroll
@@ -217,6 +217,24 @@ extern "C" int vo_match_compact(const int32_t* idx, const uint8_t* keep, int nq,
     return VO_OK;
 }
 
+int vo_launch_gen_subsets(const int32_t* n_dev, int N, int model_points, int H, const float* pts4, int batch,
+                          int32_t* samples, int32_t* n_generated, int max_attempts, hipStream_t s)
+{
+    SubsetArgs a;
+    a.n_dev = n_dev; a.pts4 = (const float4*)pts4; a.samples = samples; a.n_generated = n_generated;
+    a.N = N; a.model_points = model_points; a.H = H; a.check = pts4 != nullptr; a.max_attempts = max_attempts;
+    // a^(model_points * l) mod m by repeated multiplication with a^model_points
+    unsigned long long am = 1;
+    for (int i = 0; i < model_points; ++i) am = mulmod(am, kA);
+    a.jump[0] = 1;
+    for (int l = 1; l <= kSubsetThreads; ++l) a.jump[l] = mulmod(a.jump[l - 1], am);
+    if (model_points == 4) hipLaunchKernelGGL(gen_subsets_kernel<4>, dim3(batch), dim3(kSubsetThreads), 0, s, a);
+    else if (model_points == 5) hipLaunchKernelGGL(gen_subsets_kernel<5>, dim3(batch), dim3(kSubsetThreads), 0, s, a);
+    else hipLaunchKernelGGL(gen_subsets_kernel<7>, dim3(batch), dim3(kSubsetThreads), 0, s, a);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}
+
 extern "C" int vo_gen_subsets_device(const int32_t* n_dev, int N, int model_points, int H, const float* pts4,
                                      int batch, int32_t* samples, int32_t* n_generated, void* stream)
 {
@@ -224,18 +242,5 @@ extern "C" int vo_gen_subsets_device(const int32_t* n_dev, int N, int model_poin
                  batch <= 65535, VO_EINVAL, "vo_gen_subsets_device: bad sizes (model_points must be 4, 5 or 7)");
     if (batch == 0 || H == 0) return VO_OK;
     VO_CHECK_ARG(samples != nullptr && ((uintptr_t)pts4 & 15) == 0, VO_EINVAL, "vo_gen_subsets_device: null/unaligned pointer");
-    SubsetArgs a;
-    a.n_dev = n_dev; a.pts4 = (const float4*)pts4; a.samples = samples; a.n_generated = n_generated;
-    a.N = N; a.model_points = model_points; a.H = H; a.check = pts4 != nullptr;
-    // a^(model_points * l) mod m by repeated multiplication with a^model_points
-    unsigned long long am = 1;
-    for (int i = 0; i < model_points; ++i) am = mulmod(am, kA);
-    a.jump[0] = 1;
-    for (int l = 1; l <= kSubsetThreads; ++l) a.jump[l] = mulmod(a.jump[l - 1], am);
-    hipStream_t s = (hipStream_t)stream;
-    if (model_points == 4) hipLaunchKernelGGL(gen_subsets_kernel<4>, dim3(batch), dim3(kSubsetThreads), 0, s, a);
-    else if (model_points == 5) hipLaunchKernelGGL(gen_subsets_kernel<5>, dim3(batch), dim3(kSubsetThreads), 0, s, a);
-    else hipLaunchKernelGGL(gen_subsets_kernel<7>, dim3(batch), dim3(kSubsetThreads), 0, s, a);
-    VO_LAUNCH_CHECK();
-    return VO_OK;
+    return vo_launch_gen_subsets(n_dev, N, model_points, H, pts4, batch, samples, n_generated, 10000, (hipStream_t)stream);
 }

@@ -295,6 +295,66 @@ extern "C" int vo_ransac_batch(int kind, const int32_t* samples, int H, const vo
                                n_dev, N, batch, K4_host, thr2, mask, best_model, s);
 }
 
+// ---- frame pairs with 7..14 matches inside a batch ---------------------------------------------------
+namespace {
+int lmeds_iterations(double confidence, int max_iters)
+{
+    if (confidence < DBL_EPSILON || confidence > 1 - DBL_EPSILON) confidence = 0.99;
+    const int n = update_num_iters(confidence, 0.45, 7, max_iters);     // LMeDSPointSetRegistrator: outlier ratio 0.45 assumed
+    return n > 3 ? n : 3;
+}
+struct SmallWs { int32_t* samples; int32_t* n_lmeds; int32_t* n_small; void* ransac; size_t bytes; };
+SmallWs small_carve(void* base, int H, int batch)
+{
+    SmallWs w;
+    char* p = (char*)base;
+    size_t off = 0;
+    w.samples = (int32_t*)(p + off); off += align_up((size_t)batch * H * 7 * sizeof(int32_t));
+    w.n_lmeds = (int32_t*)(p + off); off += align_up((size_t)batch * sizeof(int32_t));
+    w.n_small = (int32_t*)(p + off); off += align_up((size_t)batch * sizeof(int32_t));
+    w.ransac = p + off; off += carve(nullptr, 3, 9, 0, H, batch).bytes;
+    w.bytes = off;
+    return w;
+}
+}  // namespace
+
+extern "C" int vo_fund_small_iterations(double confidence, int max_iters) { return lmeds_iterations(confidence, max_iters); }
+
+extern "C" size_t vo_fund_small_workspace_bytes(double confidence, int max_iters, int batch)
+{
+    if (batch <= 0) return 256;
+    return small_carve(nullptr, lmeds_iterations(confidence, max_iters), batch).bytes;
+}
+
+extern "C" int vo_fund_small_batch(const float* pts4, int N, const int32_t* n_match, int batch, double confidence, int max_iters,
+                                   int32_t* result, double* F, uint8_t* mask, double* models7, int32_t* nmodels7,
+                                   void* workspace, size_t workspace_bytes, void* stream)
+{
+    VO_CHECK_ARG(N > 0 && batch >= 0 && batch <= 65535, VO_EINVAL, "vo_fund_small_batch: bad sizes");
+    if (batch == 0) return VO_OK;
+    VO_CHECK_ARG(pts4 && n_match && result && F && mask && models7 && nmodels7 && ((uintptr_t)pts4 & 15) == 0, VO_EINVAL,
+                 "vo_fund_small_batch: null/unaligned pointer");
+    const int H = lmeds_iterations(confidence, max_iters);
+    VO_CHECK_ARG((long)H * batch <= 2147483647L / 32, VO_ESIZE, "vo_fund_small_batch: iterations x batch too large");
+    const SmallWs w = small_carve(workspace, H, batch);
+    VO_CHECK_ARG(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= w.bytes, VO_EWORKSPACE,
+                 "vo_fund_small_batch: workspace of %zu bytes (16-byte aligned) required, got %zu", w.bytes, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const RansacWs r = carve(w.ransac, 3, 9, 0, H, batch);
+    VO_HIP_TRY(hipMemsetAsync((char*)w.ransac + r.zero_from, 0, r.zero_bytes, s));
+    VO_HIP_TRY(hipMemsetAsync(nmodels7, 0, (size_t)batch * sizeof(int32_t), s));
+    int rc = vo_launch_small_prepare(n_match, batch, H, w.n_lmeds, w.n_small, nullptr, s);
+    if (rc != VO_OK) return rc;
+    // LMedS draws through getSubset's default of 1000 attempts (the RANSAC registrator passes 10000)
+    rc = vo_launch_gen_subsets(w.n_lmeds, N, 7, H, pts4, batch, w.samples, nullptr, 1000, s);
+    if (rc != VO_OK) return rc;
+    rc = vo_launch_small_prepare(n_match, batch, H, nullptr, nullptr, w.samples, s);       // identity sample where n == 7
+    if (rc != VO_OK) return rc;
+    rc = vo_launch_solve_7pt(w.samples, H * batch, H, pts4, N, w.n_small, r.models, r.nmodels, r.list, r.nlist, 0, H, nullptr, s);
+    if (rc != VO_OK) return rc;
+    return vo_launch_small_finish(r.models, r.nmodels, H, pts4, N, w.n_small, batch, result, F, mask, models7, nmodels7, s);
+}
+
 // ---- hypothesis-sharded form (one RANSAC batch over several GPUs) -----------------
 // Rank r solves and scores iterations [h_lo, h_hi) of every problem into the SAME workspace layout
 // vo_ransac_batch uses; the ranks exchange their slices of the count tables (one all_gather on the

@@ -726,6 +726,121 @@ void lmeds_median_fund_kernel(const double* __restrict__ models, const uint8_t* 
     medians[h] = __int_as_float(key[N / 2]);
 }
 
+// ---- frame pairs with 7..14 matches inside a batch (cv2.findFundamentalMat's small-input branches)
+// n_lmeds[b] = n where OpenCV runs its LMedS registrator (8..14 points), else 0 (getSubset then produces no sample);
+// n_small[b] = n for 7..14, else 0; a pair with exactly 7 matches gets the one sample 0..6 (OpenCV solves the seven
+// points as they stand)
+__global__ void small_prepare_kernel(const int32_t* __restrict__ n_match, int batch, int H, int32_t* __restrict__ n_lmeds,
+                                     int32_t* __restrict__ n_small, int32_t* __restrict__ samples)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const int n = n_match[b];
+    n_lmeds[b] = n >= 8 && n <= 14 ? n : 0;
+    n_small[b] = n >= 7 && n <= 14 ? n : 0;
+}
+
+__global__ void small_identity_kernel(const int32_t* __restrict__ n_match, int batch, int H, int32_t* __restrict__ samples)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch || n_match[b] != 7) return;
+    for (int i = 0; i < 7; ++i) samples[(size_t)b * H * 7 + i] = i;
+}
+
+// One wave per pair.  8..14 matches: OpenCV's LMeDSPointSetRegistrator -- every model ranked by the median of its
+// errors (element N/2 of the errors ordered as their int reinterpretation), the first strictly smallest median
+// wins, inliers lie within sigma = 2.5 * 1.4826 * (1 + 5/(n-7)) * sqrt(median) (at least 0.001), fewer than 7
+// inliers = no model.  Exactly 7 matches: all solutions of the one sample are returned (models7 / nmodels7), the
+// mask is all ones and F is the first solution.  Pairs outside 7..14 are left untouched.
+__global__ __launch_bounds__(64)
+void small_finish_kernel(const double* __restrict__ models, const int32_t* __restrict__ nmodels, int H,
+                         const float4* __restrict__ pts, int N, const int32_t* __restrict__ n_small, int32_t* __restrict__ result,
+                         double* __restrict__ Fout, uint8_t* __restrict__ mask, double* __restrict__ models7,
+                         int32_t* __restrict__ nmodels7)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = n_small[b];
+    if (n == 0) return;
+    pts += (size_t)b * N;
+    models += (size_t)b * H * 27;
+    nmodels += (size_t)b * H;
+    mask += (size_t)b * N;
+    if (n == 7) {
+        const int k = nmodels[0];
+        if (lane < 27) models7[(size_t)b * 27 + lane] = lane < 9 * k ? models[lane] : 0.;
+        if (lane < 9) Fout[(size_t)b * 9 + lane] = k > 0 ? models[lane] : 0.;
+        for (int i = lane; i < N; i += 64) mask[i] = i < 7;
+        if (lane == 0) {
+            nmodels7[b] = k;
+            int32_t* r = result + 4 * (size_t)b;
+            r[0] = k > 0 ? 0 : -1; r[1] = k > 0 ? 0 : -1; r[2] = k > 0 ? 7 : 0; r[3] = 0;
+        }
+        return;
+    }
+    // slot = 3 * iteration + model, visited in that order, 64 per trip
+    float best_med = __builtin_huge_valf();
+    int best_slot = -1;
+    for (int base = 0; base < 3 * H; base += 64) {
+        const int slot = base + lane, it = slot / 3, k = slot - 3 * it;
+        float med = __builtin_huge_valf();
+        if (slot < 3 * H && k < nmodels[it]) {
+            double F[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) F[q] = models[(size_t)slot * 9 + q];
+            int key[16];
+            for (int i = 0; i < n; ++i) {                       // insertion sort of the int keys (n <= 14)
+                const float4 v = pts[i];
+                const int e = __float_as_int(fund_err(F, v.x, v.y, v.z, v.w));
+                int j = i;
+                for (; j > 0 && key[j - 1] > e; --j) key[j] = key[j - 1];
+                key[j] = e;
+            }
+            med = __int_as_float(key[n / 2]);
+        }
+        // "median < minMedian" in slot order: the smallest median of the trip at its lowest slot, then strict <
+        float m = med;
+        int sidx = med < __builtin_huge_valf() ? slot : 0x7fffffff;      // NaN compares false: never a candidate
+        if (!(med < __builtin_huge_valf())) m = __builtin_huge_valf();
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            const float om = __shfl_xor(m, o);
+            const int os = __shfl_xor(sidx, o);
+            if (om < m || (om == m && os < sidx)) { m = om; sidx = os; }
+        }
+        if (m < best_med) { best_med = m; best_slot = sidx; }
+    }
+    const int niters = H;
+    if (best_slot < 0) {
+        for (int i = lane; i < N; i += 64) mask[i] = 0;
+        if (lane < 9) Fout[(size_t)b * 9 + lane] = 0.;
+        if (lane == 0) { int32_t* r = result + 4 * (size_t)b; r[0] = -1; r[1] = -1; r[2] = 0; r[3] = niters; }
+        return;
+    }
+    double F[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) F[q] = models[(size_t)best_slot * 9 + q];
+    double sigma = 2.5 * 1.4826 * (1. + 5. / (double)(n - 7)) * sqrt((double)best_med);
+    sigma = sigma > 0.001 ? sigma : 0.001;
+    const float thr2 = (float)(sigma * sigma);
+    int good = 0;
+    for (int i = lane; i < N; i += 64) {
+        uint8_t mm = 0;
+        if (i < n) {
+            const float4 v = pts[i];
+            mm = fund_err(F, v.x, v.y, v.z, v.w) <= thr2;
+        }
+        mask[i] = mm;
+        good += mm;
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) good += __shfl_xor(good, o);
+    if (lane < 9) Fout[(size_t)b * 9 + lane] = good >= 7 ? F[lane] : 0.;
+    if (lane == 0) {
+        int32_t* r = result + 4 * (size_t)b;
+        r[0] = good >= 7 ? best_slot / 3 : -1; r[1] = good >= 7 ? best_slot % 3 : -1; r[2] = good >= 7 ? good : 0; r[3] = niters;
+    }
+}
+
 int pick_chunk(int H, int N, int batch)
 {
     const long mblocks = (long)vo_ceil_div(H, kThreads) * batch;
@@ -908,6 +1023,30 @@ extern "C" int vo_lmeds_median_fund(const double* models, const uint8_t* valid, 
                  "vo_lmeds_median_fund: null/unaligned pointer");
     hipLaunchKernelGGL(lmeds_median_fund_kernel, dim3(vo_ceil_div(H, 64)), dim3(64), 0, (hipStream_t)stream, models,
                        valid, H, (const float4*)pts, N, medians);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}
+
+int vo_launch_small_prepare(const int32_t* n_match, int batch, int H, int32_t* n_lmeds, int32_t* n_small, int32_t* samples,
+                            hipStream_t s)
+{
+    if (batch == 0) return VO_OK;
+    if (samples)
+        hipLaunchKernelGGL(small_identity_kernel, dim3(vo_ceil_div(batch, 64)), dim3(64), 0, s, n_match, batch, H, samples);
+    else
+        hipLaunchKernelGGL(small_prepare_kernel, dim3(vo_ceil_div(batch, 64)), dim3(64), 0, s, n_match, batch, H, n_lmeds, n_small,
+                           samples);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}
+
+int vo_launch_small_finish(const double* models, const int32_t* nmodels, int H, const float* pts4, int N,
+                           const int32_t* n_small, int batch, int32_t* result, double* F, uint8_t* mask, double* models7,
+                           int32_t* nmodels7, hipStream_t s)
+{
+    if (batch == 0) return VO_OK;
+    hipLaunchKernelGGL(small_finish_kernel, dim3(batch), dim3(64), 0, s, models, nmodels, H, (const float4*)pts4, N, n_small,
+                       result, F, mask, models7, nmodels7);
     VO_LAUNCH_CHECK();
     return VO_OK;
 }

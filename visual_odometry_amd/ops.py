@@ -400,6 +400,29 @@ def ransac_mask_models(kind: int, best_model: torch.Tensor, result: torch.Tensor
     return mask
 
 
+def fund_small_batch(pts4: torch.Tensor, n_match: torch.Tensor, confidence: float, max_iters: int, result: torch.Tensor,
+                     F: torch.Tensor, mask: torch.Tensor, workspace: Optional[torch.Tensor] = None):
+    """cv2.findFundamentalMat's small-input branches for the pairs of a batch with 7..14 matches (LMedS for 8..14,
+    all 7-point solutions for exactly 7), written INTO result (B,4) / F (B,9) / mask (B,N) -- rows of other pairs
+    stay as they are.  -> models7 (B,3,9) f64, nmodels7 (B,) i32 (non-zero only where n_match == 7)."""
+    _lib.require_device()
+    lib = _lib.load()
+    pts4 = _dev(pts4, torch.float32, "pts4"); n_match = _dev(n_match, torch.int32, "n_match")
+    B, N = pts4.shape[0], pts4.shape[1]
+    for t, shape, dt, name in ((result, (B, 4), torch.int32, "result"), (F, (B, 9), torch.float64, "F"), (mask, (B, N), torch.uint8, "mask")):
+        if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or not t.is_cuda:
+            raise _lib.VoError(f"fund_small_batch: {name} must be a contiguous device tensor {shape} {dt}")
+    models7 = torch.zeros((B, 3, 9), dtype=torch.float64, device=pts4.device)
+    nmodels7 = torch.empty((B,), dtype=torch.int32, device=pts4.device)
+    need = lib.vo_fund_small_workspace_bytes(float(confidence), int(max_iters), B)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty((need,), dtype=torch.uint8, device=pts4.device)
+    _lib.check(lib.vo_fund_small_batch(_ptr(pts4), N, _ptr(n_match), B, float(confidence), int(max_iters), _ptr(result), _ptr(F),
+                                       _ptr(mask), _ptr(models7), _ptr(nmodels7), _ptr(workspace),
+                                       workspace.numel() * workspace.element_size(), _stream()), "vo_fund_small_batch")
+    return models7, nmodels7
+
+
 def match_compact(idx: torch.Tensor, keep: torch.Tensor, kp_q: torch.Tensor, kp_t: torch.Tensor,
                   xyz_q: Optional[torch.Tensor] = None, want_pts4: bool = True):
     """idx (B,nq,2) i32, keep (B,nq) u8, kp_q (B,nq,2) f32, kp_t (B,nt,2) f32, xyz_q (B,nq,3) f32 | None

@@ -42,6 +42,8 @@ class PairBatchResult:
     p_samples: Optional[torch.Tensor] = None
     obj: Optional[torch.Tensor] = None           # (B,nq,3) f32 / (B,nq,2) f32: the PnP correspondences
     img: Optional[torch.Tensor] = None
+    f7_models: Optional[torch.Tensor] = None     # (B,3,9) f64 every 7-point solution of the pairs with EXACTLY 7 matches (cv2 stacks them)
+    f7_count: Optional[torch.Tensor] = None      # (B,) i32 how many (0 for every other pair)
     desc_flags: Optional[torch.Tensor] = None    # (2,) i32 VO_DESC_BAD_* bits of the query / train descriptors: callers
                                                  # MUST check it (check_descriptors) where they synchronise anyway --
                                                  # the int8 matcher is only exact for integer 0..255 rows of norm <= 1024
@@ -112,6 +114,15 @@ def _split_workspace(workspace, nq, nt, f_iters, p_iters, batch):
     return flat[:nk], flat[nk:nk + nf], (flat[nk + nf:nk + nf + np_] if np_ else None)
 
 
+def _small_pairs(pts4, n, f_confidence, f_iters, f_res, F, f_mask, ws_f):
+    """Pairs with 7..14 matches, where cv2.findFundamentalMat does not run 7-point RANSAC: LMedS for 8..14, the plain
+    7-point solutions for exactly 7 (ops.fund_small_batch), written into the F batch's outputs on the same stream.
+    The F run's workspace is free again by then and is re-used when it is large enough."""
+    need = ops._lib.load().vo_fund_small_workspace_bytes(float(f_confidence), int(f_iters), pts4.shape[0])
+    ws = ws_f if ws_f is not None and ws_f.numel() >= need else None
+    return ops.fund_small_batch(pts4, n, f_confidence, f_iters, f_res, F, f_mask, workspace=ws)
+
+
 def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Tensor, kp_t: torch.Tensor, ratio: float,
                      f_threshold: float, f_confidence: float, f_iters: int,
                      xyz_q: Optional[torch.Tensor] = None, K=None, p_threshold: float = 1.0, p_confidence: float = 0.9999,
@@ -125,9 +136,9 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
     lets the small, latency-bound PnP kernels of one batch fill the gaps of the next batch's big ones.
 
     Per pair the RANSAC runs see exactly the correspondences, in the order, that the reference's
-    gathers would hand to cv2 -- so results equal the single-pair entry points'.  Pairs with fewer
-    than 15 (F) / 5 (PnP) matches get no model (the reference's cv2 calls switch algorithm or fail
-    there).
+    gathers would hand to cv2 -- so results equal the single-pair entry points', including cv2's small-input
+    branches of findFundamentalMat: LMedS for 8..14 matches, and for exactly 7 all solutions of the seven points
+    (f7_models / f7_count; F holds the first).  Fewer than 7 (F) / 5 (PnP) matches: no model.
 
     group (parallel.WORLD or a process group): ONE batch over several GPUs -- every rank passes the same
     inputs and gets the same outputs; see match_and_ransac_sharded."""
@@ -168,8 +179,9 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
     f_samples, _ = ops.gen_subsets_device(n_f, nq, 7, f_iters, c["pts4"])
     f_res, F, _, f_mask = ops.ransac_batch(ops.KIND_FUND, f_samples, c["pts4"], f_threshold, f_confidence, f_iters,
                                            n_dev=n_f, workspace=ws_f, first_block=first_block_f)
+    f7, n7 = _small_pairs(c["pts4"], n, f_confidence, f_iters, f_res, F, f_mask, ws_f)
     out = PairBatchResult(idx, d2, c["match_q"], c["match_t"], n, c["pts4"], f_res, F, f_mask, f_samples=f_samples,
-                          desc_flags=flags)
+                          desc_flags=flags, f7_models=f7, f7_count=n7)
     if do_pnp:
         out.pnp_done = side.record_event()
         if wait_pnp:
@@ -218,8 +230,9 @@ def match_and_ransac_sharded(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: t
     f_samples, _ = ops.gen_subsets_device(n_f, nq, 7, f_iters, c["pts4"])
     f_res, F, _, f_mask = par.ransac_batch_sharded(ops.KIND_FUND, f_samples, c["pts4"], f_threshold, f_confidence, f_iters,
                                                    n_dev=n_f, workspace=ws_f, group=group)
+    f7, n7 = _small_pairs(c["pts4"], n, f_confidence, f_iters, f_res, F, f_mask, ws_f)         # replicated: O(pairs) work
     out = PairBatchResult(idx, d2, c["match_q"], c["match_t"], n, c["pts4"], f_res, F, f_mask, f_samples=f_samples,
-                          desc_flags=flags)
+                          desc_flags=flags, f7_models=f7, f7_count=n7)
     if do_pnp:
         n_p = torch.where(n >= 5, n, torch.zeros_like(n))
         p_samples, _ = ops.gen_subsets_device(n_p, nq, 4, p_iters, None)
@@ -254,29 +267,13 @@ def match_and_ransac_sharded(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: t
 
 
 def finish_small_pairs(res: PairBatchResult, f_threshold: float, f_confidence: float, f_iters: int) -> int:
-    """Pairs with 8..14 matches: cv2.findFundamentalMat runs its LMedS registrator there, which
-    the fused batch does not (it leaves them without a model).  This reads `n_match` back (one host
-    synchronisation), runs the single-pair entry point -- device 7-point solver and median ranking -- for
-    those pairs only and writes F, mask and result into `res`.  Returns how many pairs it handled.  Pairs
-    with exactly 7 matches keep "no model": OpenCV returns every 7-point solution stacked there, which a
-    (B,9) model array cannot hold."""
-    from . import ransac
-    res.check_descriptors()                      # this call synchronises anyway
-    n = res.n_match.cpu().numpy()
-    small = [int(b) for b in range(len(n)) if 8 <= n[b] <= 14]
-    for b in small:
-        p = res.pts4[b, :n[b]].cpu().numpy()
-        F, mask, info = ransac.find_fundamental_ransac(p[:, :2], p[:, 2:], f_threshold, f_confidence, f_iters)
-        res.f_mask[b].zero_()
-        res.F[b].zero_()
-        if mask is not None:
-            res.f_mask[b, :n[b]] = torch.from_numpy(mask.ravel().astype("uint8")).to(res.f_mask.device)
-        if F is not None:
-            res.F[b] = torch.from_numpy(F.reshape(9)).to(res.F.device)
-        # no F (e.g. the LMedS winner has fewer than 7 inliers): "no model", so that pose_tail gives the identity
-        row = [info.best_iter, info.best_model, info.max_good, info.niters] if F is not None else [-1, -1, 0, info.niters]
-        res.f_result[b] = torch.tensor(row, dtype=torch.int32, device=res.f_result.device)
-    return len(small)
+    """Host-side check point after a batch (one synchronisation): raises if the descriptor conversion flagged bad
+    input (check_descriptors) and returns how many pairs went through cv2.findFundamentalMat's small-input branches
+    (7..14 matches).  Those branches themselves now run inside the batch (ops.fund_small_batch: LMedS for 8..14,
+    the plain 7-point solutions for 7); the arguments are kept for callers of the round-1 signature."""
+    res.check_descriptors()
+    n = res.n_match.cpu()
+    return int(((n >= 7) & (n <= 14)).sum())
 
 
 def pose_tail(res: PairBatchResult, K, max_depth: Optional[float] = None):

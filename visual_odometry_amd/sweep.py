@@ -110,7 +110,7 @@ def run_sweep(pair_ids: Sequence[int], nq: int, nt: int, batch: int, dev: torch.
                                       xyz_q=st("xyz_q"), K=K, p_threshold=p_threshold, p_confidence=p_confidence,
                                       p_iters=p_iters, first_block_pnp=first_block_pnp,
                                       workspace=ws if len(ids) == batch else None)
-        pipeline.finish_small_pairs(r, f_threshold, f_confidence, f_iters)      # 8..14 matches: OpenCV's LMedS branch
+        pipeline.finish_small_pairs(r, f_threshold, f_confidence, f_iters)      # host check point: raises on flagged descriptors
         tail = pipeline.pose_tail(r, K, max_depth)
         n = r.n_match.cpu().numpy()
         fr, pr = r.f_result.cpu().numpy(), r.p_result.cpu().numpy()
