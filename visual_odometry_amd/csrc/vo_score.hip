@@ -225,6 +225,33 @@ __device__ __forceinline__ void fund_filter32_signs(const FundFilter32& f, float
     out_bits = __builtin_amdgcn_alignbit(out_bits, __float_as_uint(r_out), 31);
 }
 
+#ifdef VO_SCORE_STATS
+__device__ unsigned long long g_stats[8];
+extern "C" int vo_score_stats(unsigned long long* out8, int reset)
+{
+    if (reset) { unsigned long long z[8] = {}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof z); }
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stats), 8 * sizeof(unsigned long long));
+}
+#endif
+// First half of that test alone: min(den1, den2) <= den2, so "d^2 - mm > thi den2" already proves "sure outlier"
+// and needs neither F^T x2 nor den1 -- 14 VALU instructions instead of 24.  It settles ~97 % of the evaluations
+// of a RANSAC batch (hypotheses are mostly wrong, thresholds tight); the rest is taken through fund_filter32
+// afterwards, per lane, from a bit string (score_kernel).  Same domain rules as fund_filter32_signs.
+__device__ __forceinline__ void fund_filter32_outlier_sign(const FundFilter32& f, float x1, float y1, float x2, float y2,
+                                                           uint32_t& out_bits)
+{
+    const float* F = f.F;
+    const float a1 = __builtin_fmaf(F[0], x1, __builtin_fmaf(F[1], y1, F[2]));
+    const float b1 = __builtin_fmaf(F[3], x1, __builtin_fmaf(F[4], y1, F[5]));
+    const float c1 = __builtin_fmaf(F[6], x1, __builtin_fmaf(F[7], y1, F[8]));
+    const float den2 = __builtin_fmaf(a1, a1, b1 * b1);
+    const float d = __builtin_fmaf(x2, a1, __builtin_fmaf(y2, b1, c1));
+    const float mm = __builtin_fmaf(f.eta2, fabsf(d), f.c);
+    const float nhi = __builtin_fmaf(-d, d, mm);
+    const float r_out = __builtin_fmaf(f.thi, den2, nhi);          // < 0: d^2 - mm > thi den2 >= thi min(den1, den2)
+    out_bits = __builtin_amdgcn_alignbit(out_bits, __float_as_uint(r_out), 31);
+}
+
 // EMEstimatorCallback::computeError: Sampson distance on normalised coordinates
 __device__ __forceinline__ float sampson_err(const double* E, double ax, double ay, double bx, double by)
 {
@@ -384,7 +411,7 @@ __global__ __launch_bounds__(kThreads, VO_SCORE_MINW)
 void score_kernel(const ScoreArgs a)
 {
     constexpr int MW = KIND == kPnp ? 12 : 9;
-    __shared__ __attribute__((aligned(16))) double sp[kMaxChunk * 4];
+    __shared__ __attribute__((aligned(16))) double sp[KIND == kFund ? kMaxChunk * 2 : kMaxChunk * 4];
     const int b = blockIdx.z;
     const int n = a.n_dev ? min(a.n_dev[b], a.N) : a.N;
     const int p0 = blockIdx.y * a.chunk;
@@ -482,7 +509,122 @@ void score_kernel(const ScoreArgs a)
         // threshold falls outside its domain takes every correspondence to tier 2 instead (force)
         const bool fast = tame_chunk != 0.;                                         // workgroup-uniform
         const uint32_t force = (__builtin_isinf(f32.eta2) || !(a.thr2 >= 0x1p-60f && a.thr2 <= 0x1p40f)) ? 0xffffffffu : 0u;
-        for (int i0 = 0; i0 < np; i0 += 32) {
+        // Full blocks of 64 correspondences of a tame chunk.
+        //   tier 1a: the one-sided sure-outlier test for every correspondence (14 instructions, sign bits);
+        //   tier 1b: the complete f32 filter for the ~2.5 % that survive it.  Survivors are very unevenly spread over
+        //            the models (a lane's own list is 10.7 entries long at the worst lane of a wave, 1.6 on average), so
+        //            the wave pools them: every lane appends its (model lane, correspondence) pairs to a list in LDS,
+        //            then lane l takes entries l, l + 64, ... whatever model they belong to, reading that model's
+        //            filter constants from LDS, and adds the verdict to the owner's LDS counter / undecided bits;
+        //   tier 2:  the f64 filter and the exact evaluation for what even that cannot decide, by the owner lane.
+        // A block with more survivors than the list holds is taken by the owners themselves, one per lane per trip.
+        int i0 = 0;
+        if (fast) {
+            constexpr int kWaves = kThreads / 64, kListCap = 512;
+            __shared__ __attribute__((aligned(16))) float wflt[kWaves][64][16];
+            __shared__ uint16_t wlist[kWaves][kListCap];
+            __shared__ int wcnt[kWaves][64];
+            __shared__ unsigned long long wund[kWaves][64];
+            __shared__ uint32_t wtot[kWaves];
+            const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            {
+                float4* o = (float4*)wflt[w][lane];
+                o[0] = make_float4(f32.F[0], f32.F[1], f32.F[2], f32.F[3]);
+                o[1] = make_float4(f32.F[4], f32.F[5], f32.F[6], f32.F[7]);
+                o[2] = make_float4(f32.F[8], f32.eta2, f32.c, f32.thi);
+                o[3] = make_float4(f32.tlo, 0.f, 0.f, 0.f);
+                wcnt[w][lane] = 0;
+                wund[w][lane] = 0;
+                if (lane == 0) wtot[w] = 0;
+            }
+            const auto tier2 = [&](const float4 v) {
+                const int verdict = fund_filter(M, ff, v.x, v.y, v.z, v.w);
+                int in = verdict > 0;
+                if (verdict == 0) in = fund_err(M, v.x, v.y, v.z, v.w) <= a.thr2;
+                return in;
+            };
+            // the wave's lanes talk through LDS here: LDS instructions of one wave execute in order, the fences only
+            // keep the compiler from moving them
+            const auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+            wave_sync();
+            for (; i0 + 64 <= np; i0 += 64) {
+                uint32_t o0 = 0, o1 = 0;
+#pragma unroll VO_SCORE_G
+                for (int k = 0; k < 32; ++k) {
+                    const float4 v = spf[i0 + k];
+                    fund_filter32_outlier_sign(f32, v.x, v.y, v.z, v.w, o0);
+                }
+#pragma unroll VO_SCORE_G
+                for (int k = 0; k < 32; ++k) {
+                    const float4 v = spf[i0 + 32 + k];
+                    fund_filter32_outlier_sign(f32, v.x, v.y, v.z, v.w, o1);
+                }
+                unsigned long long cand = ~(((unsigned long long)o0 << 32) | o1);      // bit 63 - k = correspondence i0 + k
+                unsigned long long und = 0;
+                if (force) { cand = 0; und = ~0ull; }          // model or threshold outside the f32 filter's domain: all to tier 2
+                if (!live) { cand = 0; und = 0; }
+                uint32_t at = atomicAdd(&wtot[w], (uint32_t)__popcll(cand));           // this lane's place in the list
+                wave_sync();
+                const uint32_t total = *(volatile uint32_t*)&wtot[w];
+                wave_sync();
+                if (lane == 0) wtot[w] = 0;
+#ifdef VO_SCORE_STATS
+                atomicAdd(&g_stats[0], (unsigned long long)__popcll(cand));
+                if (lane == 0) { atomicAdd(&g_stats[3], 1ull); atomicAdd(&g_stats[1], (unsigned long long)((total + 63) / 64)); }
+#endif
+                if (total <= (uint32_t)kListCap) {
+                    while (cand) {
+                        const int bit = __ffsll((long long)cand) - 1;
+                        cand &= cand - 1;
+                        wlist[w][at++] = (uint16_t)((lane << 6) | (63 - bit));
+                    }
+                    wave_sync();
+                    for (uint32_t e = lane; e < total; e += 64) {
+                        const uint32_t ent = wlist[w][e], m = ent >> 6, k = ent & 63;
+                        const float4* fm = (const float4*)wflt[w][m];
+                        const float4 A = fm[0], B = fm[1], C = fm[2];
+                        FundFilter32 g;
+                        g.F[0] = A.x; g.F[1] = A.y; g.F[2] = A.z; g.F[3] = A.w; g.F[4] = B.x; g.F[5] = B.y; g.F[6] = B.z; g.F[7] = B.w;
+                        g.F[8] = C.x; g.eta2 = C.y; g.c = C.z; g.thi = C.w; g.tlo = wflt[w][m][12];
+                        const float4 v = spf[i0 + k];
+                        const int verdict = fund_filter32(g, v.x, v.y, v.z, v.w);
+                        if (verdict > 0) atomicAdd(&wcnt[w][m], 1);
+                        else if (verdict == 0) atomicOr(&wund[w][m], 1ull << (63 - k));
+                    }
+                    wave_sync();
+                    const unsigned long long mine = *(volatile unsigned long long*)&wund[w][lane];
+                    if (mine) wund[w][lane] = 0;
+                    und |= mine;
+                } else {
+                    while (__any(cand != 0)) {
+                        if (cand) {
+                            const int pos = 63 - __clzll((long long)cand);
+                            cand &= ~(1ull << pos);
+                            const float4 v = spf[i0 + 63 - pos];
+                            const int verdict = fund_filter32(f32, v.x, v.y, v.z, v.w);
+                            cnt += verdict > 0;
+                            if (verdict == 0) und |= 1ull << pos;
+                        }
+                    }
+                }
+#ifdef VO_SCORE_STATS
+                atomicAdd(&g_stats[2], (unsigned long long)__popcll(und));
+#endif
+                while (__any(und != 0)) {
+#ifdef VO_SCORE_STATS
+                    if (lane == 0) atomicAdd(&g_stats[4], 1ull);
+#endif
+                    if (und) {
+                        const int pos = 63 - __clzll((long long)und);
+                        und &= ~(1ull << pos);
+                        cnt += tier2(spf[i0 + 63 - pos]);
+                    }
+                }
+            }
+            wave_sync();
+            cnt += *(volatile int*)&wcnt[w][lane];
+        }
+        for (; i0 < np; i0 += 32) {
             const int nb = min(32, np - i0);
             uint32_t bits = 0;
             auto tier1 = [&](int k) {
