@@ -335,8 +335,11 @@ def worker(args) -> int:
         sf["frac"] = sf["achieved"] / valu_peak
         sf["valu_instructions_per_evaluation"] = valu_per_eval
         sf["all_instructions_per_evaluation"] = isa.get("all_per_evaluation")
-        sf["note"] = (f"achieved = evaluations x {valu_per_eval} VALU instructions per evaluation (inner loop of the shipped "
-                      f"code object, profiles/r2_score_fund_isa.json; one lane = one model) / launch time; peak = {cus} CU x "
+        sf["note"] = (f"achieved = evaluations x {valu_per_eval} VALU instructions per evaluation (tier 1a, the one-sided "
+                      "sure-outlier test every evaluation goes through: inner loop of the shipped code object, "
+                      "profiles/r2_score_fund_isa.json; one lane = one model) / launch time; the ~2.5 % of evaluations that go on to "
+                      "the pooled f32 filter and the ~0.2 % that reach the f64 / exact tier are overhead, not counted "
+                      f"(valu_per_evaluation_from_SQ_INSTS_VALU counts everything executed); peak = {cus} CU x "
                       f"4 SIMD x 32 lanes/clk x {CLOCK_GHZ} GHz (a wave64 VALU instruction issues over 2 cycles).  The kernel "
                       "keeps 256 models in registers per workgroup and re-reads correspondences from LDS, so it is bound "
                       "by instruction issue, not by HBM (traffic = measured HBM bytes per launch)")
@@ -354,7 +357,7 @@ def worker(args) -> int:
                                       f"from HBM; not a roofline for this kernel ({HBM_PEAK_GBS:.0f} GB/s peak is never touched)")
     sf["f64_tflops_equivalent"] = evals_f * 49 / t_f / 1e12
     sf["f64_equivalent_note"] = ("49 f64 flops per evaluation of the scalar definition whose verdicts the kernel reproduces bit "
-                                 "for bit; executed as ~28 f32 instructions + rare f64 fallbacks")
+                                 "for bit; executed as ~17 f32 instructions + the filter tiers for the few near the threshold")
     sp_flops = evals_p * 30 / t_p / 1e12
     roof = {
         "score_fund": sf,

@@ -5,8 +5,9 @@ usage: isa_count.py [object file] [kernel name substring] [anchor instruction] >
 
 Unbundles the gfx950 code object of visual_odometry_amd/csrc/_obj/vo_score.o (what the Makefile links
 into the library), disassembles it with llvm-objdump, finds inside `score_kernel<0>` (the F count kernel)
-the innermost backward-branch loop that holds `v_alignbit_b32` and the most `v_fma`/`v_fmac` instructions
-(the unrolled sign-bit tier-1 filter loop) and counts its instructions by issue class.  One `ds_read_b128` = one correspondence, so
+the innermost backward-branch loop that holds `v_alignbit_b32` but no `v_min_f32` and the most `v_fma`/`v_fmac`
+instructions (the unrolled tier-1a loop: the one-sided sure-outlier test every evaluation goes through; the loop
+with v_min_f32 is the complete sign-bit filter kept for ragged tails) and counts its instructions by issue class.  One `ds_read_b128` = one correspondence, so
 "per evaluation" = per ds_read_b128 of the loop body.  bench.py multiplies the VALU figure by the
 evaluations of a launch to price the kernel against the VALU issue rate (roofline.bound = "valu-issue").
 """
@@ -67,6 +68,7 @@ def main():
     needle = sys.argv[2] if len(sys.argv) > 2 else "score_kernelILi0E"
     anchor = sys.argv[3] if len(sys.argv) > 3 else "ds_read_b128"
     marker = sys.argv[4] if len(sys.argv) > 4 else "v_alignbit_b32"     # the loop must hold this opcode (the sign-bit tier 1)
+    exclude = sys.argv[5] if len(sys.argv) > 5 else "v_min_f32"         # ... and not this one (the two-sided filter)
     ins = kernel_body(disassemble(obj), needle)
     index = {a: i for i, (a, _, _) in enumerate(ins)}
     best = None
@@ -84,6 +86,8 @@ def main():
             continue                                   # not innermost
         fmas = sum(o.startswith("v_fma") for _, o, _ in body)
         if marker and not any(o.startswith(marker) for _, o, _ in body):
+            continue
+        if exclude and any(o.startswith(exclude) for _, o, _ in body):
             continue
         if best is None or fmas > best[0]:
             best = (fmas, body)
