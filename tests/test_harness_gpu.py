@@ -48,3 +48,37 @@ def test_config3_malaga_continuous(det_math, dev, capsys):
         assert np.abs(T[:3, :3] - gt[:3, :3]).max() < 5e-3 and np.abs(T[:3, 3] - gt[:3, 3]).max() < 0.1
         assert len(inl) > 0.5 * len(p2)
     params.which_dataset(0)
+
+
+def test_tracking_1000_frames_with_keyframe_handover(det_math, dev, capsys):
+    """src/tracking.py:382-425's loop over 1000 synthetic frames: state carried frame to frame, key-frame hand-over
+    when the track thins out; every 50th frame's match and PnP are re-done by the oracle on the recorded inputs."""
+    o = det_math
+    n = 1000
+    seq = harness.Corridor(n, synth.K_MALAGA, synth.IMAGE_SIZE["malaga"], seed=11, per_frame=900)
+    sampled = list(range(25, n, 50))
+    res = harness.run_tracking(seq, record=sampled, min_tracked=300)
+    c = params.get_params().CONT_PARAMS.PNP_RANSAC_PARAMS
+    thr = params.get_params().SIFT_PARAMS.MATCHING_THRESHOLD
+    assert len(res) == n - 1
+    handovers = sum(r["handover"] for r in res)
+    assert 3 <= handovers <= n // 4, handovers
+    worst_R = worst_t = 0.0
+    for r in res:
+        gt = np.linalg.inv(seq.world_to_cam(r["frame"]))
+        worst_R = max(worst_R, np.abs(r["T"][:3, :3] - gt[:3, :3]).max())
+        worst_t = max(worst_t, np.abs(r["T"][:3, 3] - gt[:3, 3]).max())
+        assert r["n_inliers"] > 0.5 * r["n_matched"] > 50, r["frame"]
+    assert worst_R < 5e-3 and worst_t < 0.15, (worst_R, worst_t)
+    checked = 0
+    for r in res:
+        if r["frame"] not in sampled:
+            continue
+        oq, ot, _, _ = o.match_features_indices(r["state_desc"], r["frame_desc"], thr)
+        assert np.array_equal(oq, r["rows"])
+        oT, oinl = o.pnp(r["pts2d"], r["pts3d"], seq.K, c.NUM_ITERATIONS, c.THRESHOLD, c.CONFIDENCE)
+        assert r["inliers"] is not None and np.array_equal(r["inliers"], oinl)
+        assert np.allclose(r["T"], oT, rtol=1e-6, atol=1e-9)
+        checked += 1
+    assert checked == len(sampled)
+    params.which_dataset(0)
