@@ -327,6 +327,20 @@ int vo_host_epnp(const double* obj_host, const double* img_host, int n, const do
                  double* R9_host, double* t3_host);
 
 /* ------------------------------------------------------------------------------------
+ * Synthetic inputs (no counterpart in the reference, which reads datasets and runs cv2.SIFT: neither exists
+ * here).  Generators of the offline sweep (visual_odometry_amd/sweep.py), HBM-write bound.  Every value is a pure
+ * function of (keys[b], stream_id, element index), so a pair's data does not depend on its batch.
+ * vo_synth_sift_like: out (batch x n x 128 f32) = SIFT-like integer rows (Gamma(0.6)-like magnitudes, normalise,
+ * clip 0.2, renormalise, x512, round, saturate).  vo_synth_noisy_copies: train[b, dst[b,m]] = saturate(round(
+ * query[b, src[b,m]] + sigma N(0,1))) for m < nmatch; src / dst are batch x nmatch int64 row numbers (rows outside
+ * their set are skipped).  keys: batch int64 on the device.
+ * ---------------------------------------------------------------------------------- */
+int vo_synth_sift_like(const int64_t* keys, int batch, int n, uint64_t stream_id, float* out, void* stream);
+int vo_synth_noisy_copies(const int64_t* keys, int batch, const float* query, int nq, const int64_t* src,
+                          const int64_t* dst, int nmatch, uint64_t stream_id, float sigma, float* train, int nt,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Measurement aid (no counterpart in the reference): HIP-event timing of single launches inside
  * the entry points above, on the stream they run on.  stage_mask bits: 0 solve, 1 score, 2 replay,
  * 3 mask (inside vo_ransac_batch; tag = kind | iteration-block index << 8), 4 the kNN sweep kernel

@@ -569,3 +569,30 @@ def lmeds_median_fund(models: torch.Tensor, pts4: torch.Tensor, valid: Optional[
 def update_num_iters(p: float, ep: float, model_points: int, max_iters: int) -> int:
     """OpenCV's RANSACUpdateNumIters (host helper of the library)."""
     return int(_lib.load().vo_host_update_num_iters(float(p), float(ep), int(model_points), int(max_iters)))
+
+
+# ---- synthetic inputs (sweep.py's generators; no counterpart in the reference) ---------------------------
+def synth_sift_like(keys: torch.Tensor, n: int, stream_id: int) -> torch.Tensor:
+    """(B,) int64 pair keys -> (B,n,128) f32 SIFT-like integer rows; value = f(key, stream_id, element index)."""
+    lib = _lib.load()
+    _lib.require_device()
+    keys = _dev(keys, torch.int64, "keys")
+    out = torch.empty((keys.numel(), int(n), 128), dtype=torch.float32, device=keys.device)
+    _lib.check(lib.vo_synth_sift_like(_ptr(keys), keys.numel(), int(n), int(stream_id), _ptr(out), _stream()), "vo_synth_sift_like")
+    return out
+
+
+def synth_noisy_copies(keys: torch.Tensor, query: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, stream_id: int,
+                       sigma: float, train: torch.Tensor) -> torch.Tensor:
+    """train[b, dst[b,m]] = saturate(round(query[b, src[b,m]] + sigma N(0,1))) in place; src/dst (B,nmatch) int64."""
+    lib = _lib.load()
+    _lib.require_device()
+    keys, query, train = _dev(keys, torch.int64, "keys"), _dev(query, torch.float32, "query"), _dev(train, torch.float32, "train")
+    src, dst = _dev(src, torch.int64, "src"), _dev(dst, torch.int64, "dst")
+    B = keys.numel()
+    if query.ndim != 3 or train.ndim != 3 or query.shape[0] != B or train.shape[0] != B or query.shape[2] != 128 or \
+            train.shape[2] != 128 or src.shape != dst.shape or src.shape[0] != B:
+        raise _lib.VoError("synth_noisy_copies: query (B,nq,128), train (B,nt,128), src/dst (B,nmatch)")
+    _lib.check(lib.vo_synth_noisy_copies(_ptr(keys), B, _ptr(query), query.shape[1], _ptr(src), _ptr(dst), src.shape[1],
+                                         int(stream_id), float(sigma), _ptr(train), train.shape[1], _stream()), "vo_synth_noisy_copies")
+    return train
