@@ -395,7 +395,7 @@ def worker(args) -> int:
         "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
         "dtype": "i8 (matching) / f64 (RANSAC; F scoring filtered in f32, verdicts identical)",
         "data": "synthetic",
-        "config": {"workload": wl, "pairs_per_step": B if shard else None, "pairs_per_gpu_per_step": None if shard else B,
+        "config": {"workload": wl, "pairs_per_step": B if shard else B * world, "pairs_per_gpu_per_step": None if shard else B,
                    "mode": args.mode, "parallelism": par_note, "process_group": f"nccl (RCCL), world size {world}"},
         "ransac_scoring": {"metric": "RANSAC hypotheses x points scored/sec",
                            "value": evals_f / t_f,
