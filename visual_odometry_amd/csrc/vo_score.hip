@@ -24,6 +24,12 @@
 #ifndef VO_SCORE_MINW
 #define VO_SCORE_MINW 1               // launch-bounds hint: waves per SIMD the register budget must allow
 #endif
+#ifndef VO_SCORE_MINW_F
+#define VO_SCORE_MINW_F 5             // the F count kernel: 5 waves per SIMD (96 VGPRs; the f64 tiers are a call and spill around it)
+#endif
+#ifndef VO_SCORE_CONST_LDS
+#define VO_SCORE_CONST_LDS 1          // 1: tier 1b reads the models' f32 filter constants from LDS (12 KB) instead of lane shuffles
+#endif
 #ifndef VO_SCORE_ABLATE
 #define VO_SCORE_ABLATE 0             // scripts/score_ablate.sh: 1 = filter only, never the exact path
 #endif
@@ -388,6 +394,23 @@ __global__ void init_counts_kernel(const uint8_t* __restrict__ valid, const int3
     counts[i] = ok ? 0 : -1;
 }
 
+// Tiers 2 and 3 for one (model, correspondence) pair, model read from global memory.  Deliberately NOT inlined:
+// it runs for ~0.2 % of the evaluations, and inlined its ~50 live doubles set the register budget of the whole
+// count kernel (104 VGPRs = 4 waves per SIMD instead of 6); as a call, the few registers the hot loop keeps live
+// are saved around it instead.
+__device__ __attribute__((noinline)) int fund_decide64(const double* __restrict__ model, float x1, float y1, float x2, float y2,
+                                                       float thr2, double Q1, double Q2)
+{
+    double Mm[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Mm[k] = model[k];
+    const FundFilter g = fund_filter_setup(Mm, (double)thr2, Q1, Q2);
+    const int verdict = fund_filter(Mm, g, x1, y1, x2, y2);
+    int in = verdict > 0;
+    if (verdict == 0) in = fund_err(Mm, x1, y1, x2, y2) <= thr2;
+    return in;
+}
+
 // ---- count kernel (one template for the three error functions) -----------------------------
 enum { kFund = 0, kEss = 1, kPnp = 2 };
 
@@ -407,7 +430,7 @@ struct ScoreArgs {
 };
 
 template <int KIND>
-__global__ __launch_bounds__(kThreads, VO_SCORE_MINW)
+__global__ __launch_bounds__(kThreads, KIND == 0 ? VO_SCORE_MINW_F : VO_SCORE_MINW)
 void score_kernel(const ScoreArgs a)
 {
     constexpr int MW = KIND == kPnp ? 12 : 9;
@@ -496,17 +519,26 @@ void score_kernel(const ScoreArgs a)
             p2 = fmax(p2, o2);
             tame_chunk = fmin(tame_chunk, sscale[2][w]);
         }
-        const FundFilter ff = fund_filter_setup(M, (double)a.thr2, p1, p2);
+        // The f64 model is only needed to set the filters up and in the rare f64 tiers, which re-read it from
+        // global memory (L2) when they run: holding 9 + 5 doubles per lane through the whole kernel costs two waves
+        // per SIMD of occupancy, and this kernel needs its waves (5.45 ms at 5 per SIMD, 6.96 ms at 3).
         const FundFilter32 f32 = fund_filter32_setup(M, a.thr2, p1, p2);
+        const double* const my_model = a.models + gslot * 9;
         const float4* spf = (const float4*)sp;
-        // Blocks of 32 correspondences.  Tier 1: the f32 filter for every correspondence, branch-free;
-        // a lane that "cannot tell" only sets a bit.  Tier 2, once per block: while any lane has bits,
-        // each such lane takes one of ITS correspondences through the f64 filter and, if that still
-        // cannot tell (within rounding distance of the threshold, or degenerate), the exact
-        // evaluation.  Lanes wait for each other only for the longest bit list of the block, about
-        // one entry per block on image-like data.  A lane without a model (all-zero M) never asks.
-        // sign-bit form of tier 1 (see fund_filter32_signs) for full blocks of tame chunks; a lane whose model or
-        // threshold falls outside its domain takes every correspondence to tier 2 instead (force)
+        const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        // owner-lane tier 2 over a bit string (bit nb-1-k = correspondence first + k): the paths that are not pooled
+        const auto own_tier2 = [&](unsigned long long bits, int first, int nb) {
+            while (__any(bits != 0)) {
+                if (bits) {
+                    const int pos = 63 - __clzll((long long)bits);
+                    bits &= ~(1ull << pos);
+                    const float4 v = spf[first + nb - 1 - pos];
+                    cnt += fund_decide64(my_model, v.x, v.y, v.z, v.w, a.thr2, p1, p2);
+                }
+            }
+        };
+        // sign-bit forms of tier 1 for full blocks of tame chunks (see fund_filter32_signs); a lane whose model or
+        // threshold falls outside their domain takes every correspondence to tier 2 instead (force)
         const bool fast = tame_chunk != 0.;                                         // workgroup-uniform
         const uint32_t force = (__builtin_isinf(f32.eta2) || !(a.thr2 >= 0x1p-60f && a.thr2 <= 0x1p40f)) ? 0xffffffffu : 0u;
         // Full blocks of 64 correspondences of a tame chunk.
@@ -514,39 +546,111 @@ void score_kernel(const ScoreArgs a)
         //   tier 1b: the complete f32 filter for the ~2.5 % that survive it.  Survivors are very unevenly spread over
         //            the models (a lane's own list is 10.7 entries long at the worst lane of a wave, 1.6 on average), so
         //            the wave pools them: every lane appends its (model lane, correspondence) pairs to a list in LDS,
-        //            then lane l takes entries l, l + 64, ... whatever model they belong to, reading that model's
-        //            filter constants from LDS, and adds the verdict to the owner's LDS counter / undecided bits;
-        //   tier 2:  the f64 filter and the exact evaluation for what even that cannot decide, by the owner lane.
+        //            then lane l takes entries l, l + 64, ... whatever model they belong to, fetching that model's
+        //            filter constants from the owner lane's registers (ds_bpermute), and adds the verdict to the
+        //            owner's LDS counter or queues the pair for tier 2;
+        //   tier 2:  the f64 filter and the exact evaluation for what even that cannot decide (0.23 %): queued per
+        //            wave and worked off 64 pairs at a time, one per lane, the model re-read from global memory.
         // A block with more survivors than the list holds is taken by the owners themselves, one per lane per trip.
         int i0 = 0;
         if (fast) {
-            constexpr int kWaves = kThreads / 64, kListCap = 512;
-            __shared__ __attribute__((aligned(16))) float wflt[kWaves][64][16];
-            __shared__ uint16_t wlist[kWaves][kListCap];
+            // kListCap: survivors one block may add to the tier-1b queue (127 can be waiting); the tier-2 queue takes
+            // at most 128 per flush1 on top of the 63 it may keep
+            constexpr int kWaves = kThreads / 64, kListCap = 384, kQueueCap = 192;
+            __shared__ uint16_t wlist[kWaves][128 + kListCap]; // tier-1b queue: (model lane << 9) | correspondence of the chunk
+            __shared__ uint16_t wq2[kWaves][kQueueCap];       // tier-2 queue, same entries
             __shared__ int wcnt[kWaves][64];
-            __shared__ unsigned long long wund[kWaves][64];
-            __shared__ uint32_t wtot[kWaves];
-            const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            __shared__ uint32_t wslot[kWaves][64];            // model slot of every lane, for the tier-2 re-read
+            __shared__ uint32_t wtot[kWaves], wq2n[kWaves];
+#if VO_SCORE_CONST_LDS
+            __shared__ __attribute__((aligned(16))) float wflt[kWaves][64][12];   // F[9], eta2, c of every lane's model
             {
                 float4* o = (float4*)wflt[w][lane];
                 o[0] = make_float4(f32.F[0], f32.F[1], f32.F[2], f32.F[3]);
                 o[1] = make_float4(f32.F[4], f32.F[5], f32.F[6], f32.F[7]);
-                o[2] = make_float4(f32.F[8], f32.eta2, f32.c, f32.thi);
-                o[3] = make_float4(f32.tlo, 0.f, 0.f, 0.f);
-                wcnt[w][lane] = 0;
-                wund[w][lane] = 0;
-                if (lane == 0) wtot[w] = 0;
+                o[2] = make_float4(f32.F[8], f32.eta2, f32.c, 0.f);
             }
-            const auto tier2 = [&](const float4 v) {
-                const int verdict = fund_filter(M, ff, v.x, v.y, v.z, v.w);
-                int in = verdict > 0;
-                if (verdict == 0) in = fund_err(M, v.x, v.y, v.z, v.w) <= a.thr2;
-                return in;
+#endif
+            wcnt[w][lane] = 0;
+            wslot[w][lane] = (uint32_t)gslot;
+            if (lane == 0) { wtot[w] = 0; wq2n[w] = 0; }
+            const auto flush2 = [&](uint32_t take, uint32_t base) {
+                if ((uint32_t)lane < take) {
+                    const uint32_t ent = wq2[w][base + lane];
+                    const int m = ent >> 9, i = ent & 511;
+                    const float4 v = spf[i];
+                    if (fund_decide64(a.models + (size_t)wslot[w][m] * 9, v.x, v.y, v.z, v.w, a.thr2, p1, p2)) atomicAdd(&wcnt[w][m], 1);
+#ifdef VO_SCORE_STATS
+                    atomicAdd(&g_stats[2], 1ull);
+#endif
+                }
+#ifdef VO_SCORE_STATS
+                if (lane == 0) atomicAdd(&g_stats[6], 1ull);
+#endif
+            };
+            // tier 1b for `take` (<= 128) queued pairs starting at `base`: lane l takes entries l and l + 64 -- two
+            // independent dependency chains per lane, the loop is bound by LDS round trips, not by issue
+            const auto flush1 = [&](uint32_t take, uint32_t base) {
+                bool has[2];
+                uint32_t ent[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    has[j] = (uint32_t)(lane + 64 * j) < take;
+                    ent[j] = has[j] ? wlist[w][base + lane + 64 * j] : 0u;
+                }
+                int verdict[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int m = ent[j] >> 9, i = ent[j] & 511;
+                    FundFilter32 g;
+#if VO_SCORE_CONST_LDS
+                    {
+                        const float4* fm = (const float4*)wflt[w][m];
+                        const float4 A = fm[0], B = fm[1], C = fm[2];
+                        g.F[0] = A.x; g.F[1] = A.y; g.F[2] = A.z; g.F[3] = A.w; g.F[4] = B.x; g.F[5] = B.y; g.F[6] = B.z; g.F[7] = B.w;
+                        g.F[8] = C.x; g.eta2 = C.y; g.c = C.z;
+                    }
+#else
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) g.F[q] = __shfl(f32.F[q], m);
+                    g.eta2 = __shfl(f32.eta2, m); g.c = __shfl(f32.c, m);
+#endif
+                    g.thi = f32.thi; g.tlo = f32.tlo;                                  // functions of the threshold alone
+                    const float4 v = spf[i];
+                    verdict[j] = fund_filter32(g, v.x, v.y, v.z, v.w);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (has[j]) {
+                        const int m = ent[j] >> 9;
+                        if (verdict[j] > 0) atomicAdd(&wcnt[w][m], 1);
+#if VO_SCORE_ABLATE != 5               // timing experiment: pooled tier 1b, nothing queued for tier 2
+                        else if (verdict[j] == 0) wq2[w][atomicAdd(&wq2n[w], 1u)] = (uint16_t)ent[j];
+#endif
+                    }
+                }
+#ifdef VO_SCORE_STATS
+                if (lane == 0) atomicAdd(&g_stats[1], 1ull);
+#endif
             };
             // the wave's lanes talk through LDS here: LDS instructions of one wave execute in order, the fences only
             // keep the compiler from moving them
             const auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+            const auto drain2 = [&](uint32_t keep) {        // work the tier-2 queue off while it holds more than `keep` entries
+                uint32_t queued = __builtin_amdgcn_readfirstlane(*(volatile uint32_t*)&wq2n[w]);
+                if (queued > keep) {
+                    do {
+                        const uint32_t take = min(queued, 64u);
+                        queued -= take;
+                        flush2(take, queued);
+                    } while (queued > keep);
+                    wave_sync();
+                    if (lane == 0) wq2n[w] = queued;
+                    wave_sync();
+                }
+            };
             wave_sync();
+            uint32_t q1 = 0;                                 // wave-uniform: entries waiting in the tier-1b queue
             for (; i0 + 64 <= np; i0 += 64) {
                 uint32_t o0 = 0, o1 = 0;
 #pragma unroll VO_SCORE_G
@@ -563,39 +667,47 @@ void score_kernel(const ScoreArgs a)
                 unsigned long long und = 0;
                 if (force) { cand = 0; und = ~0ull; }          // model or threshold outside the f32 filter's domain: all to tier 2
                 if (!live) { cand = 0; und = 0; }
-                uint32_t at = atomicAdd(&wtot[w], (uint32_t)__popcll(cand));           // this lane's place in the list
+#if VO_SCORE_ABLATE == 3               // timing experiments only (wrong counts): tier 1a alone
+                cnt += __popcll(cand); cand = 0; und = 0;
+#endif
+                uint32_t at = atomicAdd(&wtot[w], (uint32_t)__popcll(cand));           // this lane's place in the queue
                 wave_sync();
-                const uint32_t total = *(volatile uint32_t*)&wtot[w];
-                wave_sync();
-                if (lane == 0) wtot[w] = 0;
+                const uint32_t q1new = __builtin_amdgcn_readfirstlane(*(volatile uint32_t*)&wtot[w]);
 #ifdef VO_SCORE_STATS
                 atomicAdd(&g_stats[0], (unsigned long long)__popcll(cand));
-                if (lane == 0) { atomicAdd(&g_stats[3], 1ull); atomicAdd(&g_stats[1], (unsigned long long)((total + 63) / 64)); }
+                if (lane == 0) atomicAdd(&g_stats[3], 1ull);
 #endif
-                if (total <= (uint32_t)kListCap) {
+                if (q1new - q1 <= (uint32_t)kListCap) {
+                    const int idx0 = (lane << 9) | (i0 + 63);
                     while (cand) {
                         const int bit = __ffsll((long long)cand) - 1;
                         cand &= cand - 1;
-                        wlist[w][at++] = (uint16_t)((lane << 6) | (63 - bit));
+                        wlist[w][at++] = (uint16_t)(idx0 - bit);                        // (model lane << 9) | correspondence of the chunk
                     }
+                    q1 = q1new;
                     wave_sync();
-                    for (uint32_t e = lane; e < total; e += 64) {
-                        const uint32_t ent = wlist[w][e], m = ent >> 6, k = ent & 63;
-                        const float4* fm = (const float4*)wflt[w][m];
-                        const float4 A = fm[0], B = fm[1], C = fm[2];
-                        FundFilter32 g;
-                        g.F[0] = A.x; g.F[1] = A.y; g.F[2] = A.z; g.F[3] = A.w; g.F[4] = B.x; g.F[5] = B.y; g.F[6] = B.z; g.F[7] = B.w;
-                        g.F[8] = C.x; g.eta2 = C.y; g.c = C.z; g.thi = C.w; g.tlo = wflt[w][m][12];
-                        const float4 v = spf[i0 + k];
-                        const int verdict = fund_filter32(g, v.x, v.y, v.z, v.w);
-                        if (verdict > 0) atomicAdd(&wcnt[w][m], 1);
-                        else if (verdict == 0) atomicOr(&wund[w][m], 1ull << (63 - k));
+#if VO_SCORE_ABLATE == 4               // ... + list building
+                    cnt += at; q1 = 0;
+#endif
+                    if (q1 >= 128) {
+                        do {
+                            q1 -= 128;
+                            flush1(128, q1);
+                            wave_sync();
+                            drain2(63);                     // at most 63 + 128 entries ever wait in the tier-2 queue
+                        } while (q1 >= 128);
+                        if (lane == 0) wtot[w] = q1;
+                        wave_sync();
                     }
+#if VO_SCORE_ABLATE == 4
+                    if (lane == 0) wtot[w] = 0;
                     wave_sync();
-                    const unsigned long long mine = *(volatile unsigned long long*)&wund[w][lane];
-                    if (mine) wund[w][lane] = 0;
-                    und |= mine;
+#endif
                 } else {
+                    // more survivors in one block than the queue has room for: the owners take them, one per lane per trip
+                    wave_sync();
+                    if (lane == 0) wtot[w] = q1;
+                    wave_sync();
                     while (__any(cand != 0)) {
                         if (cand) {
                             const int pos = 63 - __clzll((long long)cand);
@@ -609,21 +721,18 @@ void score_kernel(const ScoreArgs a)
                 }
 #ifdef VO_SCORE_STATS
                 atomicAdd(&g_stats[2], (unsigned long long)__popcll(und));
+                if (lane == 0 && __any(und != 0)) atomicAdd(&g_stats[4], 1ull);
 #endif
-                while (__any(und != 0)) {
-#ifdef VO_SCORE_STATS
-                    if (lane == 0) atomicAdd(&g_stats[4], 1ull);
-#endif
-                    if (und) {
-                        const int pos = 63 - __clzll((long long)und);
-                        und &= ~(1ull << pos);
-                        cnt += tier2(spf[i0 + 63 - pos]);
-                    }
-                }
+                own_tier2(und, i0, 64);
             }
+            wave_sync();
+            if (q1) flush1(q1, 0);
+            wave_sync();
+            drain2(0);
             wave_sync();
             cnt += *(volatile int*)&wcnt[w][lane];
         }
+        // ragged tail of the chunk, and chunks that are not tame: blocks of 32, tier 2 by the owner lane
         for (; i0 < np; i0 += 32) {
             const int nb = min(32, np - i0);
             uint32_t bits = 0;
@@ -650,27 +759,10 @@ void score_kernel(const ScoreArgs a)
                 for (int k = 0; k < nb; ++k) tier1(k);
             }
             if (!live) bits = 0;
-#if VO_SCORE_ABLATE == 2               // diagnostic: count the tier-2 entries (own) and trips (wave)
-            {
-                int trips = 0;
-                for (uint32_t m = bits; __any(m != 0); m &= m - 1) ++trips;
-                cnt += (trips << 12) + (__popc(bits) << 22);
-                bits = 0;
-            }
-#elif VO_SCORE_ABLATE == 1             // timing experiment only (wrong near the threshold)
+#if VO_SCORE_ABLATE == 1               // timing experiment only (wrong near the threshold)
             bits = 0;
 #endif
-            while (__any(bits != 0)) {
-                if (bits) {
-                    const int pos = 31 - __clz(bits);
-                    bits &= ~(1u << pos);
-                    const float4 v = spf[i0 + nb - 1 - pos];
-                    const int verdict = fund_filter(M, ff, v.x, v.y, v.z, v.w);
-                    int in = verdict > 0;
-                    if (verdict == 0) in = fund_err(M, v.x, v.y, v.z, v.w) <= a.thr2;
-                    cnt += in;
-                }
-            }
+            own_tier2(bits, i0, nb);
         }
     } else if (KIND == kPnp) {
         double pm = sscale[0][0], um = sscale[1][0], tame_chunk = sscale[2][0], im = sscale[3][0];
