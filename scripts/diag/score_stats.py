@@ -24,6 +24,6 @@ L.vo_score_stats(buf, 1)
 bench.step(ps, cfg, None); torch.cuda.synchronize()
 L.vo_score_stats(buf, 0)
 cand, trips, und, blocks, trips2, exact, flushes = [int(buf[i]) for i in range(7)]
-print(f"wave-blocks {blocks}; candidates/eval {cand / (blocks * 64 * 64):.4f}; tier-1b trips per block {trips / blocks:.2f}; "
+print(f"wave-blocks {blocks}; candidates/eval {cand / (blocks * 64 * 64):.4f}; tier-1b flushes (128 pairs) per block {trips / blocks:.2f}; "
       f"undecided/eval {und / (blocks * 64 * 64):.5f}; owner-lane tier-2 trips per block {trips2 / blocks:.2f}; "
       f"pooled tier-2 flushes per block {flushes / blocks:.3f}; exact evaluations per undecided {exact / max(und, 1):.4f}")

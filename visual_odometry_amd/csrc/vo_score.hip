@@ -27,11 +27,15 @@
 #ifndef VO_SCORE_MINW_F
 #define VO_SCORE_MINW_F 5             // the F count kernel: 5 waves per SIMD (96 VGPRs; the f64 tiers are a call and spill around it)
 #endif
+#ifndef VO_SCORE_NE
+#define VO_SCORE_NE 2                 // tier 1b: queued pairs each lane works on side by side
+#endif
 #ifndef VO_SCORE_CONST_LDS
 #define VO_SCORE_CONST_LDS 1          // 1: tier 1b reads the models' f32 filter constants from LDS (12 KB) instead of lane shuffles
 #endif
 #ifndef VO_SCORE_ABLATE
-#define VO_SCORE_ABLATE 0             // scripts/score_ablate.sh: 1 = filter only, never the exact path
+#define VO_SCORE_ABLATE 0             // timing builds with WRONG counts (scripts/diag/ab_libs.sh): 1 = ragged tails never reach tier 2;
+                                      // 3 = tier 1a alone; 4 = + queue building; 5 = + tier 1b, nothing reaches tier 2
 #endif
 
 namespace {
@@ -556,8 +560,9 @@ void score_kernel(const ScoreArgs a)
         if (fast) {
             // kListCap: survivors one block may add to the tier-1b queue (127 can be waiting); the tier-2 queue takes
             // at most 128 per flush1 on top of the 63 it may keep
-            constexpr int kWaves = kThreads / 64, kListCap = 384, kQueueCap = 192;
-            __shared__ uint16_t wlist[kWaves][128 + kListCap]; // tier-1b queue: (model lane << 9) | correspondence of the chunk
+            constexpr int kNE = VO_SCORE_NE, kBatch = 64 * kNE;     // tier-1b pairs per lane per flush
+            constexpr int kWaves = kThreads / 64, kListCap = 384, kQueueCap = 64 + kBatch;
+            __shared__ uint16_t wlist[kWaves][kBatch + kListCap]; // tier-1b queue: (model lane << 9) | correspondence of the chunk
             __shared__ uint16_t wq2[kWaves][kQueueCap];       // tier-2 queue, same entries
             __shared__ int wcnt[kWaves][64];
             __shared__ uint32_t wslot[kWaves][64];            // model slot of every lane, for the tier-2 re-read
@@ -591,16 +596,16 @@ void score_kernel(const ScoreArgs a)
             // tier 1b for `take` (<= 128) queued pairs starting at `base`: lane l takes entries l and l + 64 -- two
             // independent dependency chains per lane, the loop is bound by LDS round trips, not by issue
             const auto flush1 = [&](uint32_t take, uint32_t base) {
-                bool has[2];
-                uint32_t ent[2];
+                bool has[kNE];
+                uint32_t ent[kNE];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < kNE; ++j) {
                     has[j] = (uint32_t)(lane + 64 * j) < take;
                     ent[j] = has[j] ? wlist[w][base + lane + 64 * j] : 0u;
                 }
-                int verdict[2];
+                int verdict[kNE];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < kNE; ++j) {
                     const int m = ent[j] >> 9, i = ent[j] & 511;
                     FundFilter32 g;
 #if VO_SCORE_CONST_LDS
@@ -620,7 +625,7 @@ void score_kernel(const ScoreArgs a)
                     verdict[j] = fund_filter32(g, v.x, v.y, v.z, v.w);
                 }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < kNE; ++j) {
                     if (has[j]) {
                         const int m = ent[j] >> 9;
                         if (verdict[j] > 0) atomicAdd(&wcnt[w][m], 1);
@@ -689,13 +694,13 @@ void score_kernel(const ScoreArgs a)
 #if VO_SCORE_ABLATE == 4               // ... + list building
                     cnt += at; q1 = 0;
 #endif
-                    if (q1 >= 128) {
+                    if (q1 >= (uint32_t)kBatch) {
                         do {
-                            q1 -= 128;
-                            flush1(128, q1);
+                            q1 -= kBatch;
+                            flush1(kBatch, q1);
                             wave_sync();
                             drain2(63);                     // at most 63 + 128 entries ever wait in the tier-2 queue
-                        } while (q1 >= 128);
+                        } while (q1 >= (uint32_t)kBatch);
                         if (lane == 0) wtot[w] = q1;
                         wave_sync();
                     }
