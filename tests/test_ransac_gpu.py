@@ -268,6 +268,95 @@ def test_score_and_mask_ess(oracle_mod, dev):
     assert np.array_equal(m, oracle_mod.find_inliers(oracle_mod.sampson_error(em[b], x1, x2), thr)[1])
 
 
+def _ess_scene(o, n, seed, n_subs=80, K=None, outlier_frac=0.3, noise_px=0.3):
+    """K-normalised f64 correspondences of a two-view scene and five-point solutions of random samples."""
+    sc = synth.two_view_scene(n, seed=seed, outlier_frac=outlier_frac, noise_px=noise_px) if K is None else \
+        synth.two_view_scene(n, K=K, seed=seed, outlier_frac=outlier_frac, noise_px=noise_px)
+    Kinv = np.linalg.inv(sc["K"])
+    x1 = (np.c_[sc["p1"].astype(np.float64), np.ones(n)] @ Kinv.T)[:, :2]
+    x2 = (np.c_[sc["p2"].astype(np.float64), np.ones(n)] @ Kinv.T)[:, :2]
+    em = np.array([E.reshape(9) for s in o.gen_subsets(n, 5, n_subs) for E in o.run5point(x1[s], x2[s])])
+    return sc, np.ascontiguousarray(x1), np.ascontiguousarray(x2), em
+
+
+def _ess_ref(o, models, x1, x2, thr):
+    with np.errstate(all="ignore"):
+        return np.array([o.find_inliers(o.sampson_error(m, x1, x2), thr)[0] for m in models])
+
+
+def test_score_ess_filter_at_every_boundary(oracle_mod, dev):
+    """The E count kernel decides most correspondences with the f32 filter on rounded coordinates and takes the rest
+    through the exact f64 Sampson distance: put the threshold ON the error of many different points (and one f32 ulp
+    either side), for the best and for a mediocre model."""
+    sc, x1, x2, em = _ess_scene(oracle_mod, 1500, 31)
+    x4 = np.ascontiguousarray(np.concatenate([x1, x2], 1))
+    counts = _ess_ref(oracle_mod, em, x1, x2, 1.0 / sc["K"][0, 0])
+    checked = 0
+    for m in (em[int(np.argmax(counts))], em[len(em) // 2]):
+        err = oracle_mod.sampson_error(m, x1, x2)
+        for e in np.sort(err)[5:1400:31]:
+            for t2 in (e, np.nextafter(e, np.float32(0)), np.nextafter(e, np.float32(np.inf))):
+                thr = float(np.sqrt(np.float64(t2)))
+                if np.float32(thr * thr) != t2 or not np.isfinite(t2) or t2 <= 0:
+                    continue
+                cnt = ops.score_ess(_d(m[None], dev), _d(x4, dev), thr).cpu().numpy()
+                assert cnt[0] == int((err <= t2).sum()), (thr, cnt[0])
+                checked += 1
+    assert checked > 40
+
+
+def test_score_ess_filter_degenerate_and_scaled(oracle_mod, dev):
+    """Zero / NaN / Inf / absurdly scaled models, zero denominators, far-away, tiny and non-finite coordinates (also
+    values f32 cannot hold): every such case must come out of the exact evaluation."""
+    sc, x1, x2, em = _ess_scene(oracle_mod, 700, 32)
+    base = em[:24].copy()
+    extra = [np.zeros(9), np.full(9, np.nan), np.full(9, np.inf)]
+    for k in range(9):
+        m = base[k].copy(); m[k] = np.nan; extra.append(m)
+        m = base[k].copy(); m[k] = np.inf; extra.append(m)
+        m = base[k].copy(); m[k] = 0.0; extra.append(m)
+    m = np.zeros(9); m[8] = 1.0; extra.append(m)                      # all four gradient terms vanish
+    m = np.zeros(9); m[2] = 1.0; m[6] = -1.0; extra.append(m)
+    scaled = [base[i] * s_ for i, s_ in enumerate([1e-300, 1e-160, 1e-150, 1e-100, 1e100, 1e150, 1e160, 1e300])]
+    mods = np.concatenate([base, np.array(extra), np.array(scaled)])
+    thr0 = 1.0 / sc["K"][0, 0]
+    seen = 0
+    for scale, poison in ((1.0, False), (1.0, True), (1e4, False), (1e-3, False)):
+        q1, q2 = x1 * scale, x2 * scale
+        if poison:
+            q1[3, 0] = np.nan; q2[10, 1] = np.inf; q1[20] = 0; q2[20] = 0; q1[21, 0] = 1e300; q2[22, 1] = 1e-320
+            q1[23, 1] = 3e38; q2[24, 0] = -1e39
+        x4 = np.ascontiguousarray(np.concatenate([q1, q2], 1))
+        for thr in (thr0 * scale, 20 * thr0 * scale, 1e-3 * thr0 * scale):
+            ref = _ess_ref(oracle_mod, mods, q1, q2, thr)
+            cnt = ops.score_ess(_d(mods, dev), _d(x4, dev), thr).cpu().numpy()
+            assert np.array_equal(cnt, ref), (scale, poison, thr, np.nonzero(cnt != ref)[0][:10])
+            seen = max(seen, int(ref.max()))
+    assert seen > 100
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_score_ess_fuzz(oracle_mod, dev, seed):
+    """random scenes, intrinsics, model scalings and thresholds (0.01 px to 30 px over the focal length): counts equal
+    the scalar definition whatever tier decides."""
+    rng = np.random.default_rng(500 + seed)
+    n = int(rng.integers(33, 2500))
+    K = [synth.K_MALAGA, synth.K_KITTI, synth.K_PARKING][seed % 3]
+    sc, x1, x2, em = _ess_scene(oracle_mod, n, 600 + seed, 60, K=K, outlier_frac=float(rng.uniform(0, 0.6)),
+                                noise_px=float(rng.uniform(0, 2)))
+    models = em * (10 ** rng.uniform(-30, 30, (len(em), 1)))          # E is defined up to scale
+    jit = em * (1 + rng.normal(0, 1e-3, em.shape))
+    models = np.concatenate([models, jit])
+    x4 = np.ascontiguousarray(np.concatenate([x1, x2], 1))
+    best = 0
+    for thr in list(10 ** rng.uniform(-2, 1.5, 4) / K[0, 0]) + [3.0 / K[0, 0]]:
+        cnt = ops.score_ess(_d(models, dev), _d(x4, dev), float(thr)).cpu().numpy()
+        ref = _ess_ref(oracle_mod, models, x1, x2, float(thr))
+        assert np.array_equal(cnt, ref), (seed, thr, np.nonzero(cnt != ref)[0][:5])
+        best = max(best, int(ref.max()))
+    assert best > 0.2 * n
+
+
 def test_replay_and_argmax(oracle_mod, dev):
     rng = np.random.default_rng(0)
     for trial in range(6):

@@ -141,7 +141,8 @@ struct FundFilter32 {
     float tlo, thi, eta2, c;           // thr2 -+ 2^-17 thr2 (rounded outwards), 2 eta, constant term of m
 };
 
-__device__ __forceinline__ FundFilter32 fund_filter32_setup(const double* F, float thr2, double Q1, double Q2)
+template <bool SAMPSON>
+__device__ __forceinline__ FundFilter32 filter32_setup(const double* F, float thr2, double Q1, double Q2)
 {
     FundFilter32 f;
     double fm = 0.;
@@ -166,17 +167,24 @@ __device__ __forceinline__ FundFilter32 fund_filter32_setup(const double* F, flo
         A[k] = fabs(g);
     }
     const double S = (A[0] + A[1] + A[3] + A[4]) * Q2 * Q1 + (A[2] + A[5]) * Q2 + (A[6] + A[7]) * Q1 + A[8];
-    const double eta = 0x1p-20 * S;
-    const double al2 = 0x1p-21 * fmax((A[0] + A[1]) * Q1 + A[2], (A[3] + A[4]) * Q1 + A[5]);
-    const double al1 = 0x1p-21 * fmax((A[0] + A[3]) * Q2 + A[6], (A[1] + A[4]) * Q2 + A[7]);
+    // SAMPSON (essential matrix on K-normalised f64 coordinates): the coordinates are rounded to f32 as well, one more
+    // 2^-24 per factor of every term, and the denominator is the SUM of the four squares -- eta and alpha doubled
+    const double eta = (SAMPSON ? 0x1p-19 : 0x1p-20) * S;
+    const double al2 = (SAMPSON ? 0x1p-20 : 0x1p-21) * fmax((A[0] + A[1]) * Q1 + A[2], (A[3] + A[4]) * Q1 + A[5]);
+    const double al1 = (SAMPSON ? 0x1p-20 : 0x1p-21) * fmax((A[0] + A[3]) * Q2 + A[6], (A[1] + A[4]) * Q2 + A[7]);
     const double up = 1. + 0x1p-20;                              // constants are rounded to f32: round up
     const float inf = __builtin_huge_valf();
     const double al = fmax(al1, al2);
     f.tlo = (float)((double)thr2 * (1. - 0x1p-17) * (1. - 0x1p-20));
     f.thi = (float)((double)thr2 * (1. + 0x1p-17) * up);
     f.eta2 = usable ? (float)(2. * eta * up) : inf;
-    f.c = usable ? (float)(2. * (eta * eta + 0x1p22 * (double)thr2 * al * al) * up) : inf;
+    f.c = usable ? (float)(2. * (eta * eta + (SAMPSON ? 0x1p23 : 0x1p22) * (double)thr2 * al * al) * up) : inf;
     return f;
+}
+
+__device__ __forceinline__ FundFilter32 fund_filter32_setup(const double* F, float thr2, double Q1, double Q2)
+{
+    return filter32_setup<false>(F, thr2, Q1, Q2);
 }
 
 // d1 and d2 of fund_err are two roundings of the same number x2^T F x1, and eta bounds the distance
@@ -259,6 +267,33 @@ __device__ __forceinline__ void fund_filter32_outlier_sign(const FundFilter32& f
     const float mm = __builtin_fmaf(f.eta2, fabsf(d), f.c);
     const float nhi = __builtin_fmaf(-d, d, mm);
     const float r_out = __builtin_fmaf(f.thi, den2, nhi);          // < 0: d^2 - mm > thi den2 >= thi min(den1, den2)
+    out_bits = __builtin_amdgcn_alignbit(out_bits, __float_as_uint(r_out), 31);
+}
+
+// The Sampson distance of EMEstimatorCallback::computeError through the same kind of filter:
+//   err = d^2 / (a1^2 + b1^2 + a2^2 + b2^2),  (a1 b1 c1) = E x1,  (a2 b2 .) = E^T x2,  d = x2 . (a1 b1 c1)
+// evaluated in f32 on the f32-rounded coordinates.  With |d - d*| <= eta and every a, b within alpha of its exact
+// value, the denominator is off by at most 4 alpha sqrt(den) + 4 alpha^2 + 2^-22 den
+// <= (2^-19 + 2^-22) den + (2^21 + 4) alpha^2 (AM-GM), so
+//   sure inlier   <=  d^2 + (2 eta |d| + c) < tlo den      sure outlier  <=  d^2 - (2 eta |d| + c) > thi den
+// with c >= eta^2 + 2^22 thr2 alpha^2 (set up with 2x that) and tlo, thi = thr2 (1 -+ 2^-17) rounded outwards, which
+// also covers the f32 rounding of the exact path's result and of this test.  Same domain rules as fund_filter32_signs.
+__device__ __forceinline__ void ess_filter32_signs(const FundFilter32& f, float x1, float y1, float x2, float y2,
+                                                   uint32_t& in_bits, uint32_t& out_bits)
+{
+    const float* F = f.F;
+    const float a1 = __builtin_fmaf(F[0], x1, __builtin_fmaf(F[1], y1, F[2]));
+    const float b1 = __builtin_fmaf(F[3], x1, __builtin_fmaf(F[4], y1, F[5]));
+    const float c1 = __builtin_fmaf(F[6], x1, __builtin_fmaf(F[7], y1, F[8]));
+    const float d = __builtin_fmaf(x2, a1, __builtin_fmaf(y2, b1, c1));
+    const float a2 = __builtin_fmaf(F[0], x2, __builtin_fmaf(F[3], y2, F[6]));
+    const float b2 = __builtin_fmaf(F[1], x2, __builtin_fmaf(F[4], y2, F[7]));
+    const float den = __builtin_fmaf(a1, a1, __builtin_fmaf(b1, b1, __builtin_fmaf(a2, a2, b2 * b2)));
+    const float mm = __builtin_fmaf(f.eta2, fabsf(d), f.c);
+    const float lo = __builtin_fmaf(d, d, mm), nhi = __builtin_fmaf(-d, d, mm);
+    const float r_in = __builtin_fmaf(-f.tlo, den, lo);
+    const float r_out = __builtin_fmaf(f.thi, den, nhi);
+    in_bits = __builtin_amdgcn_alignbit(in_bits, __float_as_uint(r_in), 31);
     out_bits = __builtin_amdgcn_alignbit(out_bits, __float_as_uint(r_out), 31);
 }
 
@@ -448,6 +483,7 @@ void score_kernel(const ScoreArgs a)
     const int np = min(a.chunk, n - p0);
 
     __shared__ double sscale[4][kThreads / 64];
+    __shared__ float4 sef[KIND == kEss ? kMaxChunk : 1];      // E: the chunk's coordinates rounded to f32
     if (KIND == kFund) {
         const float4* pts = (const float4*)a.pts + (size_t)b * a.N + p0;
         double p1 = 1., p2 = 1.;                   // chunk-wide bounds on max(|x|,|y|,1) of either image
@@ -470,8 +506,27 @@ void score_kernel(const ScoreArgs a)
             sscale[0][threadIdx.x >> 6] = p1; sscale[1][threadIdx.x >> 6] = p2; sscale[2][threadIdx.x >> 6] = tame ? 1. : 0.;
         }
     } else if (KIND == kEss) {
+        // f64 coordinates for the exact path, their f32 roundings for the filter, chunk-wide bounds as for F
         const double* pts = (const double*)a.pts + ((size_t)b * a.N + p0) * 4;
-        for (int i = threadIdx.x; i < np * 4; i += kThreads) sp[i] = pts[i];
+        double p1 = 1., p2 = 1.;
+        bool tame = true;
+        for (int i = threadIdx.x; i < np; i += kThreads) {
+            const double x1 = pts[4 * i], y1 = pts[4 * i + 1], x2 = pts[4 * i + 2], y2 = pts[4 * i + 3];
+            sp[4 * i] = x1; sp[4 * i + 1] = y1; sp[4 * i + 2] = x2; sp[4 * i + 3] = y2;
+            sef[i] = make_float4((float)x1, (float)y1, (float)x2, (float)y2);
+            p1 = fmax(p1, fmax(fabs(x1), fabs(y1)));
+            p2 = fmax(p2, fmax(fabs(x2), fabs(y2)));
+            tame = tame && fabs(x1) <= 0x1p20 && fabs(y1) <= 0x1p20 && fabs(x2) <= 0x1p20 && fabs(y2) <= 0x1p20;
+        }
+        for (int o = 32; o; o >>= 1) {
+            const double o1 = __shfl_xor(p1, o), o2 = __shfl_xor(p2, o);
+            p1 = fmax(p1, o1);
+            p2 = fmax(p2, o2);
+        }
+        tame = __all(tame);
+        if ((threadIdx.x & 63) == 0) {
+            sscale[0][threadIdx.x >> 6] = p1; sscale[1][threadIdx.x >> 6] = p2; sscale[2][threadIdx.x >> 6] = tame ? 1. : 0.;
+        }
     } else {
         // 32 B per correspondence, all f32 (the object points are f32 to begin with): (X Y Z ux) (uy iu iv -), with
         // u = (float)(iu - cx), (float)(iv - cy) for the filter tier; plus the chunk-wide bounds the filter needs
@@ -809,18 +864,43 @@ void score_kernel(const ScoreArgs a)
         }
         for (; i0 < np; ++i0) cnt += exact(i0);
     } else {
-        auto one = [&](int i) {
+        double q1 = sscale[0][0], q2 = sscale[1][0], tame_chunk = sscale[2][0];
+#pragma unroll
+        for (int w = 1; w < kThreads / 64; ++w) {
+            q1 = fmax(q1, sscale[0][w]); q2 = fmax(q2, sscale[1][w]);
+            tame_chunk = fmin(tame_chunk, sscale[2][w]);
+        }
+        auto exact = [&](int i) -> int {
             const double2 u = *(const double2*)(sp + 4 * i);
             const double2 v = *(const double2*)(sp + 4 * i + 2);
-            cnt += sampson_err(M, u.x, u.y, v.x, v.y) <= a.thr2;
+            return sampson_err(M, u.x, u.y, v.x, v.y) <= a.thr2;
         };
-        // four correspondences per trip: the loop bookkeeping (and the LDS wait) is paid once per four
-        // error evaluations; each evaluation itself is unchanged
-        int i = 0;
-        for (; i + 4 <= np; i += 4) {
-            one(i); one(i + 1); one(i + 2); one(i + 3);
+        const FundFilter32 ef = filter32_setup<true>(M, a.thr2, q1, q2);
+        const bool fast = tame_chunk != 0.;                                         // workgroup-uniform
+        const uint32_t force = (__builtin_isinf(ef.eta2) || !(a.thr2 >= 0x1p-60f && a.thr2 <= 0x1p40f)) ? 0xffffffffu : 0u;
+        int i0 = 0;
+        if (fast) {
+            for (; i0 + 32 <= np; i0 += 32) {
+                uint32_t in_bits = 0, out_bits = 0;
+#pragma unroll 4
+                for (int k = 0; k < 32; ++k) {
+                    const float4 v = sef[i0 + k];
+                    ess_filter32_signs(ef, v.x, v.y, v.z, v.w, in_bits, out_bits);
+                }
+                uint32_t bits = ~(in_bits | out_bits) | force;
+                cnt += __popc(in_bits & ~force);
+                if (!live) bits = 0;
+                // tier 2: the exact evaluation for what the filter could not decide, one entry per lane per trip
+                while (__any(bits != 0)) {
+                    if (bits) {
+                        const int pos = 31 - __clz(bits);
+                        bits &= ~(1u << pos);
+                        cnt += exact(i0 + 31 - pos);
+                    }
+                }
+            }
         }
-        for (; i < np; ++i) one(i);
+        for (; i0 < np; ++i0) cnt += exact(i0);
     }
     if (live && cnt) atomicAdd(a.counts + gslot, cnt);
 }
