@@ -59,6 +59,11 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* stamps,
                 if (OP == 33) asm volatile("v_div_scale_f64 %0, vcc, %0, %1, %1" : "+v"(a[i]) : "v"((double)m) : "vcc");
                 if (OP == 34) asm volatile("v_div_fixup_f64 %0, %0, %1, %2" : "+v"(a[i]) : "v"((double)m), "v"((double)c));
                 if (OP == 35) asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(*(int*)&a[i]) : "v"(it));
+                if (OP == 36) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(*(int*)&a[i]) : "v"(si), "v"(it));
+                if (OP == 37) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(*(int*)&a[i]) : "v"(si));
+                if (OP == 38) asm volatile("v_fma_f16 %0, %0, %1, %2" : "+v"(*(int*)&a[i]) : "v"(si), "v"(it));
+                if (OP == 39) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(*(float*)&a[i]) : "v"(si), "v"(it));
+                if (OP == 40) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(*(int*)&a[i]) : "v"(si));
             }
         }
     }
@@ -122,5 +127,6 @@ int main()
     run<26>("v_and_or_b32", w); run<27>("v_lshl_or_b32", w); run<28>("v_fma_f32 |abs|", w); run<29>("v_fma_f32 sgpr", w);
     run<30>("v_fmac_f32", w); run<31>("v_sub_f32", w); run<32>("v_div_fmas_f64", w); run<33>("v_div_scale_f64", w);
     run<34>("v_div_fixup_f64", w); run<35>("v_bcnt_u32_b32", w);
+    run<36>("v_pk_fma_f16", w); run<37>("v_pk_mul_f16", w); run<38>("v_fma_f16", w); run<39>("v_dot2_f32_f16", w); run<40>("v_pk_max_f16", w);
     return 0;
 }

@@ -188,7 +188,9 @@ int vo_launch_replay(const int32_t* counts, const int32_t* nmodels, int n_iters,
                      int32_t* result, hipStream_t s)
 {
     if (batch == 0) return VO_OK;
-    if ((long)n_iters * max_models > 4096)
+    // measured in the pair pipeline (12 288-entry F tables beside the PnP side stream): 256 threads 9.31 ms per step,
+    // 1024 threads 9.41 -- the big workgroups wait for a whole CU
+    if ((long)n_iters * max_models > 65536)
         hipLaunchKernelGGL(ransac_replay_kernel<1024>, dim3(batch), dim3(1024), 0, s, counts, nmodels, n_iters,
                            max_models, n_points, n_dev, model_points, confidence, max_iters, result);
     else
