@@ -87,12 +87,24 @@ __host__ __device__ inline unsigned long long mulmod(unsigned long long x, unsig
     return r;
 }
 
+// x * y * 2^-64 mod m, x, y < m.  a * 2^32 = 1 (mod m), so for any X:  X = 2^32 (X >> 32) + lo32(X)
+// = 2^32 ((X >> 32) + lo32(X) a)  (mod m): one multiply-by-a step (what rng_step does to a state) divides by 2^32.
+// Two of them bring the 128-bit product down to 65 bits; the factor 2^-64 is folded into the jump table on the host.
+__device__ inline unsigned long long mulmod_redc(unsigned long long x, unsigned long long y)
+{
+    unsigned __int128 p = (unsigned __int128)x * y;
+    p = (p >> 32) + (unsigned __int128)(unsigned)p * kA;       // < 2^96 + 2^64
+    p = (p >> 32) + (unsigned __int128)(unsigned)p * kA;       // < 2^64 + 2^64
+    while (p >= kM) p -= kM;                                    // at most three times
+    return (unsigned long long)p;
+}
+
 constexpr int kSubsetThreads = 256;   // speculative samples per round and problem (4 waves)
 
 struct SubsetArgs {
     const int32_t* n_dev; const float4* pts4; int32_t* samples; int32_t* n_generated;
     int N, model_points, H, check, max_attempts;
-    unsigned long long jump[kSubsetThreads + 1];      // a^(model_points * l) mod m
+    unsigned long long jump[kSubsetThreads + 1];      // a^(model_points * l) * 2^64 mod m (see mulmod_redc)
 };
 
 // last point of the sample (near-)collinear with a pair of earlier ones, in image `off` (0 or 2)
@@ -140,7 +152,7 @@ void gen_subsets_kernel(const SubsetArgs a)
             // the first chunk is one iteration wide: thread 0 walks the generator step by step
             s = base;
         } else {
-            s = mulmod(a.jump[tid], base);
+            s = mulmod_redc(a.jump[tid], base);
         }
         const bool active = warm > 0 ? tid == 0 : done + tid < a.H;
         int sub[M];
@@ -226,7 +238,7 @@ int vo_launch_gen_subsets(const int32_t* n_dev, int N, int model_points, int H, 
     // a^(model_points * l) mod m by repeated multiplication with a^model_points
     unsigned long long am = 1;
     for (int i = 0; i < model_points; ++i) am = mulmod(am, kA);
-    a.jump[0] = 1;
+    a.jump[0] = 0ull - kM;                              // 2^64 mod m (m < 2^64 < 2 m)
     for (int l = 1; l <= kSubsetThreads; ++l) a.jump[l] = mulmod(a.jump[l - 1], am);
     if (model_points == 4) hipLaunchKernelGGL(gen_subsets_kernel<4>, dim3(batch), dim3(kSubsetThreads), 0, s, a);
     else if (model_points == 5) hipLaunchKernelGGL(gen_subsets_kernel<5>, dim3(batch), dim3(kSubsetThreads), 0, s, a);
