@@ -111,16 +111,29 @@ class PairSet:
         self.kp_q, self.kp_t, self.xyz_q = up("kp_q"), up("kp_t"), up("xyz_q")
         nbytes = pipeline.workspace_bytes(cfg["nq"], cfg["nt"], pairs, cfg["f_iters"], cfg["p_iters"])
         self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        self.prepared = [None, None]                            # descriptor prefetch buffers (step(prefetch=True))
 
 
-def step(ps: PairSet, cfg, group):
+def step(ps: PairSet, cfg, group, prefetch: bool = False):
     """One pass over all pairs; everything is enqueued, nothing is read back.  Weak mode: main stream + the
     pipeline's PnP side stream (the PnP tail of one step may still be running when the next step starts; the
-    timed region ends with a device-wide synchronize).  Shard mode: one stream, collectives inside."""
+    timed region ends with a device-wide synchronize).  Shard mode: one stream, collectives inside.
+    prefetch (weak mode): the way a driver walks through many batches -- the HBM-bound descriptor conversion of the
+    NEXT step's batch is enqueued on the prefetch stream (two buffers, used alternately) and runs underneath this
+    step's VALU-bound kernels; every step still converts one batch and consumes one conversion."""
     from visual_odometry_amd import pipeline
-    return pipeline.match_and_ransac(ps.q, ps.t, ps.kp_q, ps.kp_t, RATIO, F_THR, F_CONF, cfg["f_iters"], xyz_q=ps.xyz_q,
-                                     K=ps.K, p_threshold=P_THR, p_confidence=P_CONF, p_iters=cfg["p_iters"],
-                                     first_block_pnp=FIRST_BLOCK, workspace=ps.ws, wait_pnp=False, group=group)
+    prepared = None
+    if prefetch:
+        if ps.prepared[0] is None:                          # very first step: nothing was prefetched for it
+            ps.prepared[0] = pipeline.prepare_descriptors(ps.q, ps.t)
+        prepared = ps.prepared[0]
+    res = pipeline.match_and_ransac(ps.q, ps.t, ps.kp_q, ps.kp_t, RATIO, F_THR, F_CONF, cfg["f_iters"], xyz_q=ps.xyz_q,
+                                    K=ps.K, p_threshold=P_THR, p_confidence=P_CONF, p_iters=cfg["p_iters"],
+                                    first_block_pnp=FIRST_BLOCK, workspace=ps.ws, wait_pnp=False, group=group, prepared=prepared)
+    if prefetch:
+        ps.prepared[1] = pipeline.prepare_descriptors(ps.q, ps.t, reuse=ps.prepared[1])     # for the next step
+        ps.prepared.reverse()
+    return res
 
 
 def drop_in_latency(cfg):
@@ -250,12 +263,13 @@ def worker(args) -> int:
     dist.init_process_group("nccl", device_id=dev)            # RCCL, also with one rank
     shard = args.mode == "shard"
     group = parallel.WORLD if shard else None
+    prefetch = not shard and args.prefetch
 
     # shard mode: every rank holds the SAME batch (seed_base 0); weak mode: every rank its own pairs
     ps = PairSet(cfg, B, dev, 0 if shard else 1000 * rank)
     lib = _lib.load()
     for _ in range(args.warmup):
-        step(ps, cfg, group)
+        step(ps, cfg, group, prefetch)
     torch.cuda.synchronize()
     # HIP events around single launches inside the entry points (the scoring kernels of both RANSAC
     # runs and the kNN sweep kernel), recorded on the stream those kernels run on
@@ -265,7 +279,7 @@ def worker(args) -> int:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step(ps, cfg, group)
+        res = step(ps, cfg, group, prefetch)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -396,7 +410,7 @@ def worker(args) -> int:
         "dtype": "i8 (matching) / f64 (RANSAC; F scoring filtered in f32, verdicts identical)",
         "data": "synthetic",
         "config": {"workload": wl, "pairs_per_step": B if shard else B * world, "pairs_per_gpu_per_step": None if shard else B,
-                   "mode": args.mode, "parallelism": par_note, "process_group": f"nccl (RCCL), world size {world}"},
+                   "mode": args.mode, "descriptor_prefetch": prefetch, "parallelism": par_note, "process_group": f"nccl (RCCL), world size {world}"},
         "ransac_scoring": {"metric": "RANSAC hypotheses x points scored/sec",
                            "value": evals_f / t_f,
                            "unit": "evaluations/s per GPU inside the F scoring kernel (models that exist x correspondences)",
@@ -431,6 +445,9 @@ def main() -> int:
     ap.add_argument("--mode", choices=["weak", "shard"], default="weak")
     ap.add_argument("--pairs", type=int, default=0, help="frame pairs per GPU per step (weak) / per step (shard); 0 = the config's default")
     ap.add_argument("--inproc", action="store_true", help="be the single rank in this process (for profilers)")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="weak mode: convert the next step's descriptors underneath this step's scoring (pipeline.prepare_descriptors; "
+                         "measured neutral: 9.17 vs 9.16 ms per step, DESIGN.md section 7)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the single-pair drop_in_latency leg (profiling runs: keeps rocprofv3's per-kernel "

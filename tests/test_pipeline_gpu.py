@@ -156,6 +156,43 @@ def test_deferred_pnp_wait_gives_the_same_results(dev):
             assert np.array_equal(getattr(r, k).cpu().numpy(), v), k
 
 
+def test_prefetched_descriptors_give_the_same_results(dev):
+    """prepare_descriptors on the prefetch stream + match_and_ransac(prepared=...), with two buffers used alternately
+    over a stream of different batches and nothing waiting in between: results equal the plain calls'."""
+    B, nq, nt = 3, 1500, 1700
+    K = synth.K_MALAGA
+    sets = [[_pair(900 + 10 * s + b, nq, nt) for b in range(B)] for s in range(4)]
+    ws = torch.empty((pipeline.workspace_bytes(nq, nt, B, 300, 400),), dtype=torch.uint8, device=dev)
+    up = [[_d(np.stack([p[k] for p in pairs]), dev) for k in range(5)] for pairs in sets]
+    def run(t, prepared=None):
+        return pipeline.match_and_ransac(t[0], t[1], t[2], t[3], 0.8, 1.0, 0.999, 300, xyz_q=t[4], K=K, p_threshold=2.0,
+                                         p_confidence=0.999, p_iters=400, first_block_pnp=64, workspace=ws, wait_pnp=False,
+                                         prepared=prepared)
+    keys = ("n_match", "idx", "d2", "f_result", "F", "f_mask", "p_result", "pose", "p_mask", "pose_refined", "p_ok", "desc_flags")
+    ref = []
+    for t in up:
+        r = run(t); r.wait_pnp()
+        torch.cuda.synchronize()
+        ref.append({k: getattr(r, k).cpu().numpy() for k in keys})
+    bufs = [pipeline.prepare_descriptors(up[0][0], up[0][1]), None]
+    outs = []
+    for s_, t in enumerate(up):
+        outs.append(run(t, prepared=bufs[0]))
+        if s_ + 1 < len(up):
+            bufs[1] = pipeline.prepare_descriptors(up[s_ + 1][0], up[s_ + 1][1], reuse=bufs[1])
+            bufs.reverse()
+    for r in outs:
+        r.wait_pnp()
+    torch.cuda.synchronize()
+    for r, want in zip(outs[-1:], ref[-1:]):                  # desc_flags live in the reused buffers: only the last is intact
+        assert np.array_equal(r.desc_flags.cpu().numpy(), want["desc_flags"])
+    for r, want in zip(outs, ref):
+        for k in keys[:-1]:
+            assert np.array_equal(getattr(r, k).cpu().numpy(), want[k]), k
+    with pytest.raises(Exception):
+        run(up[0], prepared=pipeline.prepare_descriptors(up[0][0][:2], up[0][1][:2]))
+
+
 def test_small_pairs_inside_the_batch(det_math, dev):
     """Pairs with 7..14 matches inside the fused batch get what cv2.findFundamentalMat's small-input branches give
     (the oracle's restatement, and the single-pair entry point): LMedS for 8..14 matches, every 7-point solution

@@ -51,16 +51,23 @@ def thr2_of(threshold: float) -> float:
 
 
 # ------------------------------------------------------------------------------- matching
-def desc_to_i8(desc: torch.Tensor, flags: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+def desc_to_i8(desc: torch.Tensor, flags: Optional[torch.Tensor] = None,
+               out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """(n,128) f32 integer-valued descriptors -> (int8 rows, int32 squared norms, int32 flag word).
-    `flags` (1,) int32, already zero, may be passed in (the kernel only ORs into it)."""
+    `flags` (1,) int32, already zero, may be passed in (the kernel only ORs into it); `out` = ((n,128) i8, (n,) i32)
+    buffers to write into instead of new ones."""
     _lib.require_device()
     desc = _dev(desc, torch.float32, "desc")
     if desc.ndim != 2 or desc.shape[1] != 128:
         raise _lib.VoError(f"descriptors must be (n,128), got {tuple(desc.shape)}")
     n = desc.shape[0]
-    out = torch.empty((n, 128), dtype=torch.int8, device=desc.device)
-    norm = torch.empty((n,), dtype=torch.int32, device=desc.device)
+    if out is not None:
+        out, norm = _dev(out[0], torch.int8, "out rows"), _dev(out[1], torch.int32, "out norms")
+        if tuple(out.shape) != (n, 128) or tuple(norm.shape) != (n,):
+            raise _lib.VoError("desc_to_i8: out buffers must be (n,128) int8 and (n,) int32")
+    else:
+        out = torch.empty((n, 128), dtype=torch.int8, device=desc.device)
+        norm = torch.empty((n,), dtype=torch.int32, device=desc.device)
     if flags is None:
         flags = torch.zeros((1,), dtype=torch.int32, device=desc.device)
     else:

@@ -64,14 +64,29 @@ class PairBatchResult:
                                    "results would differ from cv.BFMatcher")
 
 
+@dataclass
+class PreparedDescriptors:
+    """A batch's descriptors already converted for the matcher (prepare_descriptors): lets a caller that walks
+    through many batches run the HBM-bound conversion of the NEXT batch underneath the VALU-bound scoring of the
+    current one."""
+    qi8: torch.Tensor            # (B*nq,128) i8
+    qn: torch.Tensor             # (B*nq,) i32
+    ti8: torch.Tensor
+    tn: torch.Tensor
+    flags: torch.Tensor          # (2,) i32 VO_DESC_BAD_* bits
+    shape: tuple                 # (B, nq, nt)
+    ready: "torch.cuda.Event"    # recorded behind the conversion
+    consumed: Optional["torch.cuda.Event"] = None   # recorded by match_and_ransac behind the kNN pass that read it
+
+
 _side = {}
 _SIDE_MAX = 16
 
 
-def _side_stream(dev: torch.device, main: "torch.cuda.Stream") -> "torch.cuda.Stream":
-    """The PnP chain's stream: one per (device, caller's stream), so that callers that run several
-    batches concurrently on streams of their own do not serialise their PnP chains on one."""
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), main.cuda_stream)
+def _side_stream(dev: torch.device, main: "torch.cuda.Stream", role: str = "pnp") -> "torch.cuda.Stream":
+    """The PnP chain's stream (or the descriptor prefetch stream): one per (device, caller's stream, role), so that
+    callers that run several batches concurrently on streams of their own do not serialise their side work on one."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), main.cuda_stream, role)
     if key not in _side:
         while len(_side) >= _SIDE_MAX:                 # callers that keep creating streams: drop the oldest entry
             _side.pop(next(iter(_side)))
@@ -82,6 +97,37 @@ def _side_stream(dev: torch.device, main: "torch.cuda.Stream") -> "torch.cuda.St
         prio = int(os.environ.get("VO_SIDE_PRIORITY", "0"))      # diagnostic knob only (scripts/diag/dist_hang.py)
         _side[key] = torch.cuda.Stream(device=dev, priority=prio)
     return _side[key]
+
+
+def prepare_descriptors(desc_q: torch.Tensor, desc_t: torch.Tensor, reuse: Optional[PreparedDescriptors] = None) -> PreparedDescriptors:
+    """Enqueue the int8 conversion of a batch's descriptors ((B,n,128) f32, resident) on the pipeline's prefetch
+    stream and return at once; pass the result to match_and_ransac(prepared=...).  `reuse`: a PreparedDescriptors of
+    the same shape whose buffers may be overwritten (the conversion waits until the matcher that read them is done) --
+    two of them, used alternately, pipeline a stream of batches without allocating."""
+    B, nq, nt = desc_q.shape[0], desc_q.shape[1], desc_t.shape[1]
+    main = torch.cuda.current_stream()
+    pre = _side_stream(desc_q.device, main, "prefetch")
+    pre.wait_stream(main)                                  # the inputs were produced on the caller's stream
+    if reuse is not None:
+        if reuse.shape != (B, nq, nt):
+            raise ops._lib.VoError(f"prepare_descriptors: reuse has shape {reuse.shape}, batch has {(B, nq, nt)}")
+        if reuse.consumed is not None:
+            pre.wait_event(reuse.consumed)
+    for t in (desc_q, desc_t):
+        t.record_stream(pre)
+    with torch.cuda.stream(pre):
+        if reuse is not None:
+            flags = reuse.flags.zero_()
+            qi8, qn, _ = ops.desc_to_i8(desc_q.reshape(B * nq, 128), flags[0:1], out=(reuse.qi8, reuse.qn))
+            ti8, tn, _ = ops.desc_to_i8(desc_t.reshape(B * nt, 128), flags[1:2], out=(reuse.ti8, reuse.tn))
+        else:
+            flags = torch.zeros((2,), dtype=torch.int32, device=desc_q.device)
+            qi8, qn, _ = ops.desc_to_i8(desc_q.reshape(B * nq, 128), flags[0:1])
+            ti8, tn, _ = ops.desc_to_i8(desc_t.reshape(B * nt, 128), flags[1:2])
+        ready = pre.record_event()
+    for t in (qi8, qn, ti8, tn, flags):
+        t.record_stream(main)
+    return PreparedDescriptors(qi8, qn, ti8, tn, flags, (B, nq, nt), ready)
 
 
 def workspace_bytes(nq: int, nt: int, batch: int, f_iters: int, p_iters: int = 0) -> int:
@@ -127,7 +173,8 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
                      f_threshold: float, f_confidence: float, f_iters: int,
                      xyz_q: Optional[torch.Tensor] = None, K=None, p_threshold: float = 1.0, p_confidence: float = 0.9999,
                      p_iters: int = 0, first_block_f: int = 0, first_block_pnp: int = 0,
-                     workspace: Optional[torch.Tensor] = None, wait_pnp: bool = True, group=None) -> PairBatchResult:
+                     workspace: Optional[torch.Tensor] = None, wait_pnp: bool = True, group=None,
+                     prepared: Optional[PreparedDescriptors] = None) -> PairBatchResult:
     """desc_* (B,n,128) f32 integer-valued, kp_* (B,n,2) f32, xyz_q (B,nq,3) f32 landmarks of the query
     keypoints (enables the PnP run when p_iters > 0).  first_block_*: see ops.ransac_batch (0 = evaluate all
     iterations at once).  Everything is enqueued on the current stream, except the PnP chain (P3P RANSAC +
@@ -140,6 +187,9 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
     branches of findFundamentalMat: LMedS for 8..14 matches, and for exactly 7 all solutions of the seven points
     (f7_models / f7_count; F holds the first).  Fewer than 7 (F) / 5 (PnP) matches: no model.
 
+    prepared: the descriptors' int8 conversion done ahead of time on the prefetch stream (prepare_descriptors); the
+    conversion is then not repeated here.
+
     group (parallel.WORLD or a process group): ONE batch over several GPUs -- every rank passes the same
     inputs and gets the same outputs; see match_and_ransac_sharded."""
     if group is not None:
@@ -147,12 +197,20 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
                                         p_threshold=p_threshold, p_confidence=p_confidence, p_iters=p_iters,
                                         workspace=workspace, group=group, first_block_pnp=first_block_pnp)
     B, nq, nt = desc_q.shape[0], desc_q.shape[1], desc_t.shape[1]
-    flags = torch.zeros((2,), dtype=torch.int32, device=desc_q.device)       # one fill for both conversions
-    qi8, qn, _ = ops.desc_to_i8(desc_q.reshape(B * nq, 128), flags[0:1])
-    ti8, tn, _ = ops.desc_to_i8(desc_t.reshape(B * nt, 128), flags[1:2])
+    if prepared is not None:
+        if prepared.shape != (B, nq, nt):
+            raise ops._lib.VoError(f"match_and_ransac: prepared descriptors have shape {prepared.shape}, batch has {(B, nq, nt)}")
+        torch.cuda.current_stream().wait_event(prepared.ready)
+        qi8, qn, ti8, tn, flags = prepared.qi8, prepared.qn, prepared.ti8, prepared.tn, prepared.flags
+    else:
+        flags = torch.zeros((2,), dtype=torch.int32, device=desc_q.device)       # one fill for both conversions
+        qi8, qn, _ = ops.desc_to_i8(desc_q.reshape(B * nq, 128), flags[0:1])
+        ti8, tn, _ = ops.desc_to_i8(desc_t.reshape(B * nt, 128), flags[1:2])
     do_pnp = p_iters > 0 and xyz_q is not None
     ws_k, ws_f, ws_p = _split_workspace(workspace, nq, nt, f_iters, p_iters if do_pnp else 0, B)
     idx, d2 = ops.knn2(qi8.reshape(B, nq, 128), qn.reshape(B, nq), ti8.reshape(B, nt, 128), tn.reshape(B, nt), ws_k)
+    if prepared is not None:
+        prepared.consumed = torch.cuda.current_stream().record_event()
     keep, _ = ops.ratio_test(d2.reshape(B * nq, 2), ratio)
     c = ops.match_compact(idx, keep.reshape(B, nq), kp_q, kp_t, xyz_q if p_iters > 0 else None)
     n = c["n"]
