@@ -35,7 +35,8 @@
 #endif
 #ifndef VO_SCORE_ABLATE
 #define VO_SCORE_ABLATE 0             // timing builds with WRONG counts (scripts/diag/ab_libs.sh): 1 = ragged tails never reach tier 2;
-                                      // 3 = tier 1a alone; 4 = + queue building; 5 = + tier 1b, nothing reaches tier 2
+                                      // 3 = tier 1a alone; 4 = + queue building; 5 = + tier 1b, nothing reaches tier 2;
+                                      // 8 = PnP / E: the f32 filter alone (its exact tier is 0.1 of PnP's 1.2 ms standalone)
 #endif
 
 namespace {
@@ -852,6 +853,9 @@ void score_kernel(const ScoreArgs a)
                 uint32_t bits = ~(in_bits | out_bits) | force;
                 cnt += __popc(in_bits & ~force);
                 if (!live) bits = 0;
+#if VO_SCORE_ABLATE == 8               // timing experiment (wrong counts): PnP / E filter alone
+                cnt += __popc(bits); bits = 0;
+#endif
                 // tier 2: the exact evaluation for what the filter could not decide, one entry per lane per trip
                 while (__any(bits != 0)) {
                     if (bits) {
@@ -890,6 +894,9 @@ void score_kernel(const ScoreArgs a)
                 uint32_t bits = ~(in_bits | out_bits) | force;
                 cnt += __popc(in_bits & ~force);
                 if (!live) bits = 0;
+#if VO_SCORE_ABLATE == 8               // timing experiment (wrong counts): PnP / E filter alone
+                cnt += __popc(bits); bits = 0;
+#endif
                 // tier 2: the exact evaluation for what the filter could not decide, one entry per lane per trip
                 while (__any(bits != 0)) {
                     if (bits) {
