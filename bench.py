@@ -94,21 +94,27 @@ def launcher(args, argv) -> int:
 
 # ----------------------------------------------------------------------------------------- worker
 class PairSet:
-    """Device-resident inputs of `pairs` frame pairs (a few distinct seeds, tiled)."""
+    """Device-resident inputs of `pairs` DISTINCT frame pairs: the first four from the host generator (synth.frame_pair,
+    the pairs the CPU baseline runs), the rest from the device generator of the same recipe (sweep.frame_pairs_device)."""
 
-    def __init__(self, cfg, pairs: int, dev, seed_base: int, distinct: int = 4):
+    def __init__(self, cfg, pairs: int, dev, seed_base: int, host_pairs: int = 4):
         import numpy as np
         import torch
-        from visual_odometry_amd import pipeline, synth
-        distinct = min(distinct, pairs)
+        from visual_odometry_amd import pipeline, sweep, synth
+        host_pairs = min(host_pairs, pairs)
         K, size = synth.K_MALAGA, synth.IMAGE_SIZE["malaga"]
         made = [synth.frame_pair(cfg["nq"], cfg["nt"], seed=1234 + seed_base + d, K=K, size=size,
-                                 landmark_outlier_frac=cfg["landmark_outliers"]) for d in range(distinct)]
-        sel = [i % distinct for i in range(pairs)]
-        up = lambda key: torch.from_numpy(np.stack([made[i][key] for i in sel])).to(dev)
+                                 landmark_outlier_frac=cfg["landmark_outliers"]) for d in range(host_pairs)]
+        keys = ("q", "t", "kp_q", "kp_t", "xyz_q")
+        parts = {k: [torch.from_numpy(np.stack([m[k] for m in made])).to(dev)] for k in keys}
+        for lo in range(host_pairs, pairs, 32):
+            ids = [100000 + seed_base * 1000 + i for i in range(lo, min(pairs, lo + 32))]
+            g = sweep.frame_pairs_device(ids, cfg["nq"], cfg["nt"], K, size, dev, landmark_outlier_frac=cfg["landmark_outliers"])
+            for k in keys:
+                parts[k].append(g[k])
         self.pairs, self.K = pairs, K
-        self.q, self.t = up("q"), up("t")                       # (B, N, 128) f32
-        self.kp_q, self.kp_t, self.xyz_q = up("kp_q"), up("kp_t"), up("xyz_q")
+        self.q, self.t = torch.cat(parts["q"]), torch.cat(parts["t"])         # (B, N, 128) f32
+        self.kp_q, self.kp_t, self.xyz_q = torch.cat(parts["kp_q"]), torch.cat(parts["kp_t"]), torch.cat(parts["xyz_q"])
         nbytes = pipeline.workspace_bytes(cfg["nq"], cfg["nt"], pairs, cfg["f_iters"], cfg["p_iters"])
         self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         self.prepared = [None, None]                            # descriptor prefetch buffers (step(prefetch=True))
@@ -409,6 +415,8 @@ def worker(args) -> int:
         "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
         "dtype": "i8 (matching) / f64 (RANSAC; F scoring filtered in f32, verdicts identical)",
         "data": "synthetic",
+        "data_note": "every frame pair of a step is a different synthetic scene (4 from the host generator -- the ones the CPU "
+                     "baseline runs -- the rest from the device generator of the same recipe); random-init, no dataset",
         "config": {"workload": wl, "pairs_per_step": B if shard else B * world, "pairs_per_gpu_per_step": None if shard else B,
                    "mode": args.mode, "descriptor_prefetch": prefetch, "parallelism": par_note, "process_group": f"nccl (RCCL), world size {world}"},
         "ransac_scoring": {"metric": "RANSAC hypotheses x points scored/sec",
