@@ -451,6 +451,14 @@ __device__ __attribute__((noinline)) int fund_decide64(const double* __restrict_
     return in;
 }
 
+// A load of an LDS word that the compiler must not cache or hoist (another lane of the wave wrote it).  A volatile
+// access through a cast pointer loses the address space and becomes a flat_load with a full vmcnt wait.
+template <typename T>
+__device__ __forceinline__ T lds_load(T* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
 // ---- count kernel (one template for the three error functions) -----------------------------
 enum { kFund = 0, kEss = 1, kPnp = 2 };
 
@@ -698,7 +706,7 @@ void score_kernel(const ScoreArgs a)
             // keep the compiler from moving them
             const auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
             const auto drain2 = [&](uint32_t keep) {        // work the tier-2 queue off while it holds more than `keep` entries
-                uint32_t queued = __builtin_amdgcn_readfirstlane(*(volatile uint32_t*)&wq2n[w]);
+                uint32_t queued = __builtin_amdgcn_readfirstlane(lds_load(&wq2n[w]));
                 if (queued > keep) {
                     do {
                         const uint32_t take = min(queued, 64u);
@@ -733,7 +741,7 @@ void score_kernel(const ScoreArgs a)
 #endif
                 uint32_t at = atomicAdd(&wtot[w], (uint32_t)__popcll(cand));           // this lane's place in the queue
                 wave_sync();
-                const uint32_t q1new = __builtin_amdgcn_readfirstlane(*(volatile uint32_t*)&wtot[w]);
+                const uint32_t q1new = __builtin_amdgcn_readfirstlane(lds_load(&wtot[w]));
 #ifdef VO_SCORE_STATS
                 atomicAdd(&g_stats[0], (unsigned long long)__popcll(cand));
                 if (lane == 0) atomicAdd(&g_stats[3], 1ull);
@@ -791,7 +799,7 @@ void score_kernel(const ScoreArgs a)
             wave_sync();
             drain2(0);
             wave_sync();
-            cnt += *(volatile int*)&wcnt[w][lane];
+            cnt += lds_load(&wcnt[w][lane]);
         }
         // ragged tail of the chunk, and chunks that are not tame: blocks of 32, tier 2 by the owner lane
         for (; i0 < np; i0 += 32) {
