@@ -21,6 +21,9 @@
 #ifndef VO_SCORE_G
 #define VO_SCORE_G 8                  // unroll factor of the tier-1 loops of the F count kernel (2: 5.25 ms, 4: 4.96, 8: 4.86, 16: 5.30)
 #endif
+#ifndef VO_SCORE_GP
+#define VO_SCORE_GP 4                 // unroll factor of the PnP / E filter loops
+#endif
 #ifndef VO_SCORE_MINW
 #define VO_SCORE_MINW 1               // launch-bounds hint: waves per SIMD the register budget must allow
 #endif
@@ -852,7 +855,7 @@ void score_kernel(const ScoreArgs a)
         if (fast) {
             for (; i0 + 32 <= np; i0 += 32) {
                 uint32_t in_bits = 0, out_bits = 0;
-#pragma unroll 4
+#pragma unroll VO_SCORE_GP
                 for (int k = 0; k < 32; ++k) {
                     const float4 p = spf[2 * (i0 + k)];
                     const float uy = ((const float*)sp)[8 * (i0 + k) + 4];
@@ -894,7 +897,7 @@ void score_kernel(const ScoreArgs a)
         if (fast) {
             for (; i0 + 32 <= np; i0 += 32) {
                 uint32_t in_bits = 0, out_bits = 0;
-#pragma unroll 4
+#pragma unroll VO_SCORE_GP
                 for (int k = 0; k < 32; ++k) {
                     const float4 v = sef[i0 + k];
                     ess_filter32_signs(ef, v.x, v.y, v.z, v.w, in_bits, out_bits);
