@@ -82,3 +82,30 @@ def test_tracking_1000_frames_with_keyframe_handover(det_math, dev, capsys):
         checked += 1
     assert checked == len(sampled)
     params.which_dataset(0)
+
+
+def test_tracking_with_triangulated_landmarks(det_math, dev, capsys):
+    """The same loop as a self-contained VO: after the start-up the map only grows by triangulating matches between
+    the frame 30 back and the current one with the ESTIMATED poses (src/tracking.py:150-172 -> vo_triangulate), so
+    the trajectory drifts -- by about 1 % of the distance travelled here.  Sampled frames are re-done by the oracle."""
+    o = det_math
+    n = 400
+    seq = harness.Corridor(n, synth.K_MALAGA, synth.IMAGE_SIZE["malaga"], seed=11, per_frame=900)
+    sampled = list(range(40, n, 60))
+    res = harness.run_tracking(seq, record=sampled, min_tracked=200, new_landmarks="triangulate", track_length=30)
+    c = params.get_params().CONT_PARAMS.PNP_RANSAC_PARAMS
+    thr = params.get_params().SIFT_PARAMS.MATCHING_THRESHOLD
+    tri = [r for r in res if r["handover"] and "n_new_landmarks" in r]
+    assert len(tri) >= 20 and min(r["n_new_landmarks"] for r in tri) > 200
+    err = [np.abs(r["T"][:3, 3] - np.linalg.inv(seq.world_to_cam(r["frame"]))[:3, 3]).max() for r in res]
+    rot = [np.abs(r["T"][:3, :3] - np.linalg.inv(seq.world_to_cam(r["frame"]))[:3, :3]).max() for r in res]
+    assert max(err) < 0.03 * n * seq.step and max(rot) < 0.03, (max(err), max(rot))       # < 3 % of the 100 m driven
+    assert min(r["n_inliers"] for r in res) > 100
+    for r in res:
+        if r["frame"] in sampled:
+            oq, ot, _, _ = o.match_features_indices(r["state_desc"], r["frame_desc"], thr)
+            assert np.array_equal(oq, r["rows"])
+            oT, oinl = o.pnp(r["pts2d"], r["pts3d"], seq.K, c.NUM_ITERATIONS, c.THRESHOLD, c.CONFIDENCE)
+            assert r["inliers"] is not None and np.array_equal(r["inliers"], oinl)
+            assert np.allclose(r["T"], oT, rtol=1e-6, atol=1e-9)
+    params.which_dataset(0)

@@ -165,17 +165,29 @@ def _with_row_ids(feats: Features) -> Features:
 
 
 def run_tracking(seq: Corridor, frames: Optional[Iterable[int]] = None, dataset: int = 1, min_tracked: int = 400,
-                 landmark_noise: float = 0.01, record: Iterable[int] = ()) -> List[Dict]:
+                 landmark_noise: float = 0.01, record: Iterable[int] = (), new_landmarks: str = "truth",
+                 track_length: int = 15) -> List[Dict]:
     """Frame-to-frame localisation with key-frame hand-over (src/tracking.py:382-425's call pattern).
 
     The state is the tracked keypoints (with descriptors) and their world landmarks.  Per frame: match the state
     against the new frame (for ``klt`` + ``mask_klt``), carry the landmarks over, ``pnp``, keep the RANSAC
     inliers, drop landmarks behind the camera or farther than 100 (lines 416-425).  When fewer than
-    `min_tracked` remain, the frame becomes a key frame: its landmark-bearing features and their world points
-    (ground truth + `landmark_noise`, for the triangulation the TrackManager would do) replace the state.
+    `min_tracked` remain, the frame becomes a key frame and the state is replaced:
+      * new_landmarks="truth": by the frame's landmark-bearing features and their world points (ground truth +
+        `landmark_noise`) -- isolates the match + PnP path from map quality;
+      * new_landmarks="triangulate": by what TrackManager.get_new_landmarks would add (src/tracking.py:150-172): all
+        features of the frame `track_length` frames back (a track started there, MIN_TRACK_LENGTH's role: enough
+        baseline) are matched against this frame and triangulated between the two ESTIMATED camera poses
+        (``landmarks.triangulate_track`` -> ``vo_triangulate``), depth-filtered; until that many frames exist the
+        state is re-seeded from ground truth, which also fixes the scale (as the 2D-2D initialisation plus a known
+        baseline would).  The trajectory then drifts like a real VO's.
     -> one dict per frame: T (cam_to_world), n_state, n_matched, n_inliers, n_kept, handover; frames listed in
     `record` also keep the inputs (state / frame descriptors, pts2d, pts3d, inlier indices) for an external check."""
+    from .landmarks import triangulate_track
+    if new_landmarks not in ("truth", "triangulate"):
+        raise ValueError("new_landmarks must be 'truth' or 'triangulate'")
     params.which_dataset(dataset)
+    max_depth = params.get_params().CONT_PARAMS.MAX_DEPTH_DISTANCE
     frames = list(range(seq.n_frames) if frames is None else frames)
     record = set(record)
     rng = np.random.default_rng([seq.seed, 1 << 21])
@@ -185,7 +197,9 @@ def run_tracking(seq: Corridor, frames: Optional[Iterable[int]] = None, dataset:
         xyz = seq.landmarks[fr.landmark_id[have]] + rng.normal(0, landmark_noise, (int(have.sum()), 3))
         return _with_row_ids(Features(fr.features.keypoints[have], fr.features.descriptors[have])), xyz
 
-    state, landmarks = key_frame(seq.frame(frames[0]))
+    first = seq.frame(frames[0])
+    state, landmarks = key_frame(first)
+    past = [(first.features, np.linalg.inv(first.world_to_cam))]              # recent frames: all features + estimated pose
     out: List[Dict] = []
     for f in frames[1:]:
         fr = seq.frame(f)
@@ -206,10 +220,22 @@ def run_tracking(seq: Corridor, frames: Optional[Iterable[int]] = None, dataset:
             keep &= (P_cam[:, 2] > 0) & (np.linalg.norm(P_cam, axis=1) < 100)       # tracking.py:421-423 (4-vector norm, as there)
         rec["n_kept"] = int(keep.sum())
         if rec["n_kept"] < min_tracked:
-            state, landmarks = key_frame(fr)
             rec["handover"] = True
+            if new_landmarks == "truth" or len(past) < track_length:
+                state, landmarks = key_frame(fr)
+            else:
+                old_feats, old_pose = past[-track_length]
+                m_old, m_cur = match_features(old_feats, fr.features)
+                P_world, kp_j, mask = triangulate_track(seq.K, old_pose, T, m_old.get_positions().reshape(-1, 2),
+                                                        m_cur.get_positions().reshape(-1, 2), max_depth)
+                rec["n_new_landmarks"] = int(mask.sum())
+                state = _with_row_ids(Features(m_cur.keypoints[mask], m_cur.descriptors[mask]))
+                landmarks = P_world[:, :3]
         else:
             state = _with_row_ids(Features(mf_cur.keypoints[keep], mf_cur.descriptors[keep]))
             landmarks = pts3d[keep]
+        past.append((fr.features, T))
+        if len(past) > track_length:
+            past.pop(0)
         out.append(rec)
     return out
