@@ -87,6 +87,10 @@ int vo_ratio_test(const int32_t* d2, int n, double ratio, uint8_t* keep, int32_t
  *   cv.solvePnPRansac(..., SOLVEPNP_P3P, ...)      reference src/pnp.py:16-26
  * thr2 is (float)(threshold*threshold); a point is an inlier iff (float)err <= thr2.
  * counts[h] = number of inliers of model h, or -1 when valid[h] == 0 (valid may be NULL).
+ * The counts are those of the scalar definitions, bit for bit: the kernels settle most correspondences with
+ * division-free f32 filters whose error bounds are rigorous and evaluate the definition itself only where a
+ * filter cannot tell (within rounding distance of the threshold; zero, non-finite or absurdly scaled models and
+ * coordinates).  The vo_mask_* kernels always evaluate the definitions.
  * ---------------------------------------------------------------------------------- */
 
 /* models H x 9 f64 (row-major F), pts N x 4 f32 (x1 y1 x2 y2).  Symmetric squared
