@@ -4,8 +4,9 @@
 //
 // Every value is a pure function of (pair key, stream, element index): the hash is the one PairRng.bits of sweep.py
 // evaluates with int64 tensor ops -- splitmix64's finaliser of  key ^ mix(index * GOLD + mix(stream))  -- so both
-// generators draw the same uniforms; the float transforms behind them (logf, cosf, powf) may differ in the last
-// bit between the two, which is why sweep.py keeps to one of them per device type.
+// generators draw the same uniforms; the float transforms behind them (log, cos, pow: hardware approximations here)
+// differ by ~1e-6 relative between the two -- a different integer after the rounding for about one value in a
+// thousand -- which is why sweep.py keeps to one of them per device type.
 //
 //   vo_synth_sift_like    one wave per descriptor row, two values per lane: Gamma(0.6)-like magnitudes
 //                         (Wilson-Hilferty Gamma(1.6) x U^(1/0.6)), L2-normalise, clip 0.2, renormalise, x512,
@@ -37,10 +38,13 @@ __device__ __forceinline__ float gamma06(unsigned long long b)
     const float u1 = ((float)(b >> 43) + 0.5f) * s;
     const float u2 = ((float)((b >> 22) & 0x1FFFFF) + 0.5f) * s;
     const float u3 = ((float)((b >> 1) & 0x1FFFFF) + 0.5f) * s;
-    const float zn = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+    // hardware transcendentals (v_log_f32, v_cos_f32, v_exp_f32: ~1e-6 relative): the generator is compute bound on
+    // these, and its values are rounded to integers afterwards
+    // (v_log_f32 = log2, v_cos_f32 takes revolutions, v_exp_f32 = 2^x; every argument is a normal number in (0, 1))
+    const float zn = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
     const float c = 1.0f / (9.0f * 1.6f);
-    const float w = fmaxf(1.0f - c + sqrtf(c) * zn, 0.0f);
-    return 1.6f * (w * w * w) * powf(u3, 1.0f / 0.6f);
+    const float w = fmaxf(1.0f - c + 0.26352313834736496f * zn, 0.0f);
+    return 1.6f * (w * w * w) * __builtin_amdgcn_exp2f((1.0f / 0.6f) * __builtin_amdgcn_logf(u3));
 }
 
 __global__ __launch_bounds__(256)
@@ -67,7 +71,7 @@ void sift_like_kernel(const long long* __restrict__ keys, int n, long rows, unsi
 __device__ __forceinline__ float normal24(unsigned long long b)
 {
     const float u1 = ((float)(b >> 40) + 0.5f) * 0x1p-24f, u2 = ((float)(b & 0xFFFFFF) + 0.5f) * 0x1p-24f;
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+    return __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
 }
 
 __global__ __launch_bounds__(256)
