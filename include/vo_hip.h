@@ -340,6 +340,9 @@ int vo_host_epnp(const double* obj_host, const double* img_host, int n, const do
  * their set are skipped).  keys: batch int64 on the device.
  * ---------------------------------------------------------------------------------- */
 int vo_synth_sift_like(const int64_t* keys, int batch, int n, uint64_t stream_id, float* out, void* stream);
+/* out (batch x n int64) = the raw hash words behind the draws: splitmix64's finaliser of
+ * keys[b] ^ mix(i * 0x9E3779B97F4A7C15 + mix(stream_id)). */
+int vo_synth_hash64(const int64_t* keys, int batch, long n, uint64_t stream_id, int64_t* out, void* stream);
 int vo_synth_noisy_copies(const int64_t* keys, int batch, const float* query, int nq, const int64_t* src,
                           const int64_t* dst, int nmatch, uint64_t stream_id, float sigma, float* train, int nt,
                           void* stream);

@@ -42,3 +42,15 @@ def test_noisy_copies_kernel(dev):
     with pytest.raises(Exception):
         ops.synth_noisy_copies(torch.zeros(2, dtype=torch.int64, device=dev), p["q"], torch.zeros((2, 4), dtype=torch.int64, device=dev),
                                torch.zeros((2, 5), dtype=torch.int64, device=dev), 1, 1.0, p["t"])
+
+
+def test_hash_words_equal_the_tensor_path(dev):
+    """vo_synth_hash64 = PairRng.bits of the CPU device, word for word, so the f64 scene draws of both devices agree."""
+    ids = [0, 7, 123456, 2 ** 40 + 5]
+    g, c = sweep.PairRng(ids, 99, dev), sweep.PairRng(ids, 99, torch.device("cpu"))
+    for shape in ((1,), (3,), (1000,), (37, 128)):
+        assert np.array_equal(g.bits(*shape).cpu().numpy(), c.bits(*shape).numpy())
+    assert np.array_equal(g.uniform(500).cpu().numpy(), c.uniform(500).numpy())
+    assert np.array_equal(g.permutation(8192).cpu().numpy(), c.permutation(8192).numpy())
+    p = g.permutation(1000).cpu().numpy()
+    assert all(np.array_equal(np.sort(row), np.arange(1000)) for row in p)

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "vo_host_update_num_iters": (_i, [_d, _d, _i, _i]),
     "vo_host_epnp": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "vo_synth_sift_like": (_i, [_vp, _i, _i, C.c_uint64, _vp, _vp]),
+    "vo_synth_hash64": (_i, [_vp, _i, C.c_long, C.c_uint64, _vp, _vp]),
     "vo_synth_noisy_copies": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, C.c_uint64, _f, _vp, _i, _vp]),
     "vo_profile_enable": (_i, [_i, _i]),
     "vo_profile_collect": (_i, [_vp, _vp, _i]),

@@ -95,7 +95,31 @@ void noisy_copies_kernel(const long long* __restrict__ keys, const float* __rest
     }
 }
 
+// the hash words themselves: out[b, i] = mix(key[b] ^ mix(i * GOLD + mix(stream))), what PairRng.bits computes with a
+// dozen elementwise tensor ops -- the small per-pair draws of the scene generator are launch bound without it
+__global__ __launch_bounds__(256)
+void hash64_kernel(const long long* __restrict__ keys, long n, long total, unsigned long long stream_mix, long long* __restrict__ out)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / n, e = i - b * n;
+        out[i] = (long long)mix64((unsigned long long)keys[b] ^ mix64((unsigned long long)e * kGold + stream_mix));
+    }
+}
+
 }  // namespace
+
+extern "C" int vo_synth_hash64(const int64_t* keys, int batch, long n, uint64_t stream_id, int64_t* out, void* stream)
+{
+    VO_CHECK_ARG(batch >= 0 && n >= 0, VO_EINVAL, "synth: batch=%d n=%ld", batch, n);
+    const long total = (long)batch * n;
+    if (total == 0) return VO_OK;
+    VO_CHECK_ARG(keys && out, VO_EINVAL, "synth: null pointer");
+    const int grid = (int)std::min<long>((total + 255) / 256, 256L * 16);
+    hipLaunchKernelGGL(hash64_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const long long*)keys, n, total,
+                       mix64(stream_id), (long long*)out);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}
 
 extern "C" int vo_synth_sift_like(const int64_t* keys, int batch, int n, uint64_t stream_id, float* out, void* stream)
 {

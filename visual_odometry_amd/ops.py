@@ -589,6 +589,16 @@ def synth_sift_like(keys: torch.Tensor, n: int, stream_id: int) -> torch.Tensor:
     return out
 
 
+def synth_hash64(keys: torch.Tensor, n: int, stream_id: int) -> torch.Tensor:
+    """(B,) int64 pair keys -> (B,n) int64 hash words (sweep.PairRng.bits in one launch)."""
+    lib = _lib.load()
+    _lib.require_device()
+    keys = _dev(keys, torch.int64, "keys")
+    out = torch.empty((keys.numel(), int(n)), dtype=torch.int64, device=keys.device)
+    _lib.check(lib.vo_synth_hash64(_ptr(keys), keys.numel(), int(n), int(stream_id), _ptr(out), _stream()), "vo_synth_hash64")
+    return out
+
+
 def synth_noisy_copies(keys: torch.Tensor, query: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, stream_id: int,
                        sigma: float, train: torch.Tensor) -> torch.Tensor:
     """train[b, dst[b,m]] = saturate(round(query[b, src[b,m]] + sigma N(0,1))) in place; src/dst (B,nmatch) int64."""
