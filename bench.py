@@ -395,6 +395,10 @@ def worker(args) -> int:
                  "units_per_launch": f"{B} frame pairs of {nq_local} x {NT} descriptors"},
     }
     roof["knn2"]["frac"] = roof["knn2"]["achieved"] / i8_peak_tops
+    if kc("knn2_partial_kernel").get("clock_ghz"):
+        ck = kc("knn2_partial_kernel")["clock_ghz"]
+        roof["knn2"]["clock_ghz_under_load"] = ck
+        roof["knn2"]["frac_at_measured_clock"] = roof["knn2"]["achieved"] / (cus * I8_OPS_PER_CLK_CU * ck * 1e9 / 1e12)
     dominant = max(tot, key=tot.get)
     pairs_total = B * args.steps * (1 if shard else world)
     wl = {"cfg4": f"cfg4: {NQ}x{NT}x128 SIFT match + ratio test -> matched correspondences (on device) -> {HF}-iteration "
