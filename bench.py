@@ -71,13 +71,33 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def visible_gpus():
+    """GPUs this process may use, found WITHOUT loading torch or any HIP/HSA library (the launcher must stay
+    provably GPU-free until its children have been started): the runtime's visibility lists if set, else the KFD
+    topology in sysfs (nodes with SIMDs are GPUs).  None = cannot tell (the ranks then fail by themselves)."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for d in os.listdir(nodes):
+            with open(os.path.join(nodes, d, "properties")) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        return n
+    except (OSError, ValueError):
+        return None
+
+
 def launcher(args, argv) -> int:
-    """Start args.gpus rank processes of this script (fresh interpreters: this process never touches the
-    GPU, so nothing GPU-initialised is forked or exec'd) and wait for them."""
-    import torch
+    """Start args.gpus rank processes of this script (fresh interpreters: this process loads neither torch nor
+    HIP, so nothing GPU-initialised is forked or exec'd), watch them, and if one fails end the others instead of
+    leaving them blocked in the rendezvous or a collective."""
     n = args.gpus
-    have = torch.cuda.device_count()            # does not initialise the GPU
-    if n < 1 or n > max(have, 1):
+    have = visible_gpus()
+    if n < 1 or (have is not None and n > max(have, 1)):
         print(f"bench.py: --gpus {n} but {have} GPU(s) visible", file=sys.stderr)
         return 2
     port = _free_port()
@@ -86,9 +106,25 @@ def launcher(args, argv) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = abs(code) or 1
+                print(f"bench.py: rank process {procs.index(p)} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in live:
+                    q.terminate()
+                deadline = time.time() + 10
+                for q in live:
+                    try:
+                        q.wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
     return rc
 
 
@@ -266,7 +302,8 @@ def worker(args) -> int:
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.require_device(local)
-    dist.init_process_group("nccl", device_id=dev)            # RCCL, also with one rank
+    import datetime
+    dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))   # RCCL, also with one rank
     shard = args.mode == "shard"
     group = parallel.WORLD if shard else None
     prefetch = not shard and args.prefetch

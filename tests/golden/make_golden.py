@@ -48,6 +48,11 @@ def knn_cases():
     idx, dist = o.knn2(q, t, mt=True)
     out.update(idx4096=idx, dist4096=dist, seed4096=np.array([103]),
                checksum4096=np.array([q.sum(dtype=np.float64), t.sum(dtype=np.float64)]))
+    # 4096 x 4096 from the integer-hash generator (same bytes on every numpy): inputs regenerated, never skipped
+    q, t = synth.hashed_descriptor_pair(4096, 4096, seed=7)
+    idx, dist = o.knn2(q, t, mt=True)
+    out.update(idxh4096=idx, disth4096=dist, seedh4096=np.array([7]),
+               checksumh4096=np.array([int((q.astype(np.int64) * (np.arange(128) + 1)).sum()), int((t.astype(np.int64) * (np.arange(128) + 1)).sum())]))
     save("knn.npz", **out)
 
 

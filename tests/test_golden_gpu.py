@@ -42,6 +42,17 @@ def test_knn_4096_golden(dev):
     assert np.array_equal(idx, g["idx4096"]) and np.array_equal(dist, g["dist4096"])
 
 
+def test_knn_4096_hashed_golden(dev):
+    """The same size with inputs from the integer-hash generator: regenerated bit for bit on any numpy, so this one
+    cannot skip (a checksum mismatch is a failure)."""
+    g = load("knn.npz")
+    q, t = synth.hashed_descriptor_pair(4096, 4096, seed=int(g["seedh4096"][0]))
+    w = np.arange(128) + 1
+    assert [int((q.astype(np.int64) * w).sum()), int((t.astype(np.int64) * w).sum())] == [int(v) for v in g["checksumh4096"]]
+    idx, dist, _ = features.knn2_arrays(q, t)
+    assert np.array_equal(idx, g["idxh4096"]) and np.array_equal(dist, g["disth4096"])
+
+
 def test_scoring_golden(dev):
     g = load("scoring.npz")
     pts4 = _d(np.concatenate([g["p1"], g["p2"]], 1).astype(np.float32), dev)

@@ -287,6 +287,23 @@ def test_small_counts(oracle_mod):
     assert F is None
 
 
+def test_oracle_knn_on_hashed_4096_golden(oracle_mod):
+    """The 4096 x 4096 fixture whose inputs come from the integer-hash generator (no numpy Generator stream, so it
+    never skips): the oracle reproduces the stored table, and an independent exact-integer numpy kNN agrees."""
+    g = load("knn.npz")
+    q, t = synth.hashed_descriptor_pair(4096, 4096, seed=int(g["seedh4096"][0]))
+    w = np.arange(128) + 1
+    assert [int((q.astype(np.int64) * w).sum()), int((t.astype(np.int64) * w).sum())] == [int(v) for v in g["checksumh4096"]]
+    idx, dist = oracle_mod.knn2(q, t, mt=True)
+    assert np.array_equal(idx, g["idxh4096"]) and np.array_equal(dist, g["disth4096"])
+    qi, ti = q[:512].astype(np.int64), t.astype(np.int64)
+    D = (qi ** 2).sum(1)[:, None] + (ti ** 2).sum(1)[None, :] - 2 * qi @ ti.T
+    key = D * 8192 + np.arange(4096)[None, :]                  # ties -> lower train index
+    order = np.argsort(key, axis=1)[:, :2]
+    assert np.array_equal(order, idx[:512])
+    assert np.array_equal(np.sqrt(np.take_along_axis(D, order, 1).astype(np.float32)), dist[:512])
+
+
 # ------------------------------------------------------------------------------------ reference helpers
 def test_pose_tail_against_reference_helpers(oracle_mod):
     from visual_odometry_amd.utils.decompose_essential_matrix import decomposeEssentialMatrix

@@ -184,13 +184,41 @@ def test_prefetched_descriptors_give_the_same_results(dev):
     for r in outs:
         r.wait_pnp()
     torch.cuda.synchronize()
-    for r, want in zip(outs[-1:], ref[-1:]):                  # desc_flags live in the reused buffers: only the last is intact
-        assert np.array_equal(r.desc_flags.cpu().numpy(), want["desc_flags"])
-    for r, want in zip(outs, ref):
-        for k in keys[:-1]:
+    for r, want in zip(outs, ref):                            # desc_flags included: every result owns its flag word
+        for k in keys:
             assert np.array_equal(getattr(r, k).cpu().numpy(), want[k]), k
     with pytest.raises(Exception):
         run(up[0], prepared=pipeline.prepare_descriptors(up[0][0][:2], up[0][1][:2]))
+    with pytest.raises(Exception):                            # the sharded path takes no prepared descriptors
+        pipeline.match_and_ransac(up[0][0], up[0][1], up[0][2], up[0][3], 0.8, 1.0, 0.999, 300, group="world",
+                                  prepared=pipeline.prepare_descriptors(up[0][0], up[0][1]))
+
+
+def test_bad_descriptors_of_an_early_batch_are_reported_after_buffer_reuse(dev):
+    """Three batches through two alternating prefetch buffers, bad descriptors only in batch 0: its result must still
+    raise in check_descriptors() after all batches are enqueued (the buffer batch 0 used has been zeroed and refilled
+    for batch 2 by then), and the clean batches must not."""
+    B, nq, nt = 2, 600, 640
+    sets = [[_pair(1200 + 10 * s + b, nq, nt) for b in range(B)] for s in range(3)]
+    up = [[_d(np.stack([p[k] for p in pairs]), dev) for k in range(5)] for pairs in sets]
+    up[0][0] = up[0][0].clone(); up[0][0][1, 17, 5] = 3.5       # non-integer value in a query row of batch 0
+    up[0][1] = up[0][1].clone(); up[0][1][0, 3, :] = 255.0      # a train row of norm > 1024
+    def run(t, prepared):
+        return pipeline.match_and_ransac(t[0], t[1], t[2], t[3], 0.8, 1.0, 0.999, 100, prepared=prepared)
+    bufs = [pipeline.prepare_descriptors(up[0][0], up[0][1]), None]
+    outs = []
+    for s_, t in enumerate(up):
+        outs.append(run(t, bufs[0]))
+        if s_ + 1 < len(up):
+            bufs[1] = pipeline.prepare_descriptors(up[s_ + 1][0], up[s_ + 1][1], reuse=bufs[1])
+            bufs.reverse()
+    torch.cuda.synchronize()
+    fq, ft = (int(v) for v in outs[0].desc_flags.cpu())
+    assert fq & ops._lib.VO_DESC_BAD_VALUE and ft & ops._lib.VO_DESC_BAD_NORM
+    with pytest.raises(ops._lib.VoError):
+        outs[0].check_descriptors()
+    outs[1].check_descriptors()
+    outs[2].check_descriptors()
 
 
 def test_small_pairs_inside_the_batch(det_math, dev):

@@ -7,12 +7,14 @@ Nothing on this path needs a bulk exchange:
                                8192 rows); rows are independent, an all_gather only assembles the result;
   * one RANSAC problem      -> the hypothesis (sample) range is split over ranks, correspondences are
                                replicated (<= 640 KB).  Each rank solves and scores its slice, then ONE
-                               all_gather of the int32 inlier counts (16-256 KB in total) gives every
-                               rank the full count vector and the replay of OpenCV's sequential
+                               all_gather of the int32 inlier counts (per PROBLEM 16-256 KB in total; the
+                               batched form gathers B x H x (width + 1) int32 = 16.8 MB per cfg4 step) gives
+                               every rank the full count vector and the replay of OpenCV's sequential
                                best-model bookkeeping runs replicated -> exactly the single-GPU
                                answer.  The winning model (72-96 B) is broadcast from its owner.
     In pure-argmax mode a single packed int64 MAX all-reduce replaces the gather.
-Messages are tiny, i.e. latency-bound: batch several problems into one collective where possible.
+Per problem the messages are tiny; batched over a step's 256 problems they reach 4-17 MB per collective
+(sizes in DESIGN.md section 6) -- whether that is latency- or link-bound on xGMI is unmeasured.
 """
 from __future__ import annotations
 
@@ -68,11 +70,9 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
     pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: hi - lo] = local
     out = all_gather_stack(pad, group).reshape((world * width,) + tuple(local.shape[1:]))
-    parts = []
-    for r in range(world):
-        a, b = shard_bounds(n_total, r, world)
-        parts.append(out[r * width: r * width + (b - a)])
-    return torch.cat(parts, dim=0)
+    if n_total == world * width:
+        return out
+    return out.index_select(0, _gather_index(n_total, world, out.device))
 
 
 def pack_best(count: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
@@ -190,11 +190,25 @@ def all_gather_dim1(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
     g = all_gather_stack(pad, group)                        # (world, B, width, ...)
     if n_total == world * width:
         return g.transpose(0, 1).reshape((local.shape[0], n_total) + tuple(local.shape[2:]))
-    parts = []
-    for r in range(world):
-        a, b = shard_bounds(n_total, r, world)
-        parts.append(g[r][:, : b - a])
-    return torch.cat(parts, dim=1)
+    flat = g.transpose(0, 1).reshape((local.shape[0], world * width) + tuple(local.shape[2:]))
+    return flat.index_select(1, _gather_index(n_total, world, flat.device))
+
+
+_gather_idx = {}
+
+
+def _gather_index(n: int, world: int, device) -> torch.Tensor:
+    """Row of the rank-major padded gather buffer ((world * ceil(n / world)) rows) that holds global row i, for
+    every i < n: rank r's slice shard_bounds(n, r, world) starts at r * ceil(n / world)."""
+    key = (n, world, str(device))
+    if key not in _gather_idx:
+        per = -(-n // world)
+        idx = torch.empty((n,), dtype=torch.int64)
+        for r in range(world):
+            a, b = shard_bounds(n, r, world)
+            idx[a:b] = torch.arange(r * per, r * per + (b - a))
+        _gather_idx[key] = idx.to(device)
+    return _gather_idx[key]
 
 
 class DeviceRansacBackend:
@@ -240,12 +254,11 @@ def ransac_batch_sharded(kind: int, samples: torch.Tensor, pts: torch.Tensor, th
         send[:, : hi - lo, :width] = counts[:, lo:hi]
         send[:, : hi - lo, width] = nmodels[:, lo:hi]
         got = all_gather_stack(send, group)                 # (world, B, per, width + 1)
-        for r in range(world):
-            if r == rank:
-                continue
-            a, b = shard_bounds(H, r, world)
-            counts[:, a:b] = got[r, :, : b - a, :width]
-            nmodels[:, a:b] = got[r, :, : b - a, width]
+        # one gather along the iteration axis puts every rank's rows where the tables want them (the padded
+        # tail rows of the shorter slices are never indexed); the tables live in the workspace, so copy in place
+        full = got.permute(1, 0, 2, 3).reshape(B, world * per, width + 1).index_select(1, _gather_index(H, world, counts.device))
+        counts.copy_(full[:, :, :width])
+        nmodels.copy_(full[:, :, width])
     result, best, rvec = be.slice_finish(kind, H, lo, hi, N, B, confidence, max_iters, state, n_dev)
     if _live(group):
         if rvec is not None:

@@ -193,6 +193,10 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
     group (parallel.WORLD or a process group): ONE batch over several GPUs -- every rank passes the same
     inputs and gets the same outputs; see match_and_ransac_sharded."""
     if group is not None:
+        if prepared is not None or first_block_f != 0:
+            raise ops._lib.VoError("match_and_ransac: `prepared` and `first_block_f` are not supported together with `group` "
+                                   "(the sharded path converts its own query slice and evaluates every F iteration); "
+                                   "wait_pnp has no effect there either: everything runs on the current stream")
         return match_and_ransac_sharded(desc_q, desc_t, kp_q, kp_t, ratio, f_threshold, f_confidence, f_iters, xyz_q=xyz_q, K=K,
                                         p_threshold=p_threshold, p_confidence=p_confidence, p_iters=p_iters,
                                         workspace=workspace, group=group, first_block_pnp=first_block_pnp)
@@ -201,7 +205,10 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
         if prepared.shape != (B, nq, nt):
             raise ops._lib.VoError(f"match_and_ransac: prepared descriptors have shape {prepared.shape}, batch has {(B, nq, nt)}")
         torch.cuda.current_stream().wait_event(prepared.ready)
-        qi8, qn, ti8, tn, flags = prepared.qi8, prepared.qn, prepared.ti8, prepared.tn, prepared.flags
+        qi8, qn, ti8, tn = prepared.qi8, prepared.qn, prepared.ti8, prepared.tn
+        # this batch's own copy of the flag word (8 bytes, on the caller's stream, behind `ready`): the prefetch
+        # buffer's word is zeroed and OR-ed into again as soon as the buffer is reused for a later batch
+        flags = prepared.flags.clone()
     else:
         flags = torch.zeros((2,), dtype=torch.int32, device=desc_q.device)       # one fill for both conversions
         qi8, qn, _ = ops.desc_to_i8(desc_q.reshape(B * nq, 128), flags[0:1])

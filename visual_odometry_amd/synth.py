@@ -42,6 +42,38 @@ def sift_like_pair(nq: int, nt: int, seed: int = 1234, match_frac: float = 0.6,
     return q, t
 
 
+def _mix64(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on uint64 arrays (wrap-around integer arithmetic only)."""
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def hashed_descriptor_pair(nq: int, nt: int, seed: int = 1) -> Tuple[np.ndarray, np.ndarray]:
+    """A SIFT-shaped descriptor pair ((n,128) f32, integers 0..255, skewed towards small values, every row of
+    L2 norm < 1024) made from a counter-based integer hash ONLY -- no floating-point function and no numpy
+    Generator stream, so the same bytes come out on every numpy version and platform (golden fixtures whose
+    inputs are regenerated instead of stored).  Half of the train rows are query rows with +-8 integer noise at
+    hashed positions, the rest are fresh rows."""
+    def words(n, stream):
+        i = np.arange(n * 128, dtype=np.uint64) + np.uint64((seed * 4 + stream) << 40)
+        return _mix64(i * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0xD1B54A32D192ED03))
+
+    def rows(n, stream):
+        w = words(n, stream)
+        a, b, c = (w >> np.uint64(8)) & np.uint64(255), (w >> np.uint64(24)) & np.uint64(255), (w >> np.uint64(40)) & np.uint64(255)
+        return ((a * b * c) >> np.uint64(17)).astype(np.int64).reshape(n, 128)        # 0..126, ~cubic skew
+
+    q, t = rows(nq, 0), rows(nt, 1)
+    w = words(nt, 2).reshape(nt, 128)
+    src = (w[:, 0] >> np.uint64(20)) % np.uint64(max(nq, 1))
+    copy = ((w[:, 1] >> np.uint64(33)) & np.uint64(1)).astype(bool) if nq else np.zeros(nt, bool)
+    noise = ((w >> np.uint64(50)) % np.uint64(17)).astype(np.int64) - 8
+    noisy = np.clip(q[src.astype(np.int64)] + noise, 0, 255) if nq else t
+    t = np.where(copy[:, None], noisy, t)
+    return q.astype(np.float32), t.astype(np.float32)
+
+
 def _rodrigues(axis_angle: np.ndarray) -> np.ndarray:
     th = np.linalg.norm(axis_angle)
     if th < 1e-15:
