@@ -156,7 +156,7 @@ class PairSet:
         self.prepared = [None, None]                            # descriptor prefetch buffers (step(prefetch=True))
 
 
-def step(ps: PairSet, cfg, group, prefetch: bool = False):
+def step(ps: PairSet, cfg, group, prefetch: bool = False, pose_tail: bool = True):
     """One pass over all pairs; everything is enqueued, nothing is read back.  Weak mode: main stream + the
     pipeline's PnP side stream (the PnP tail of one step may still be running when the next step starts; the
     timed region ends with a device-wide synchronize).  Shard mode: one stream, collectives inside.
@@ -172,6 +172,10 @@ def step(ps: PairSet, cfg, group, prefetch: bool = False):
     res = pipeline.match_and_ransac(ps.q, ps.t, ps.kp_q, ps.kp_t, RATIO, F_THR, F_CONF, cfg["f_iters"], xyz_q=ps.xyz_q,
                                     K=ps.K, p_threshold=P_THR, p_confidence=P_CONF, p_iters=cfg["p_iters"],
                                     first_block_pnp=FIRST_BLOCK, workspace=ps.ws, wait_pnp=False, group=group, prepared=prepared)
+    if pose_tail:
+        # "R,t out" of the 2D-2D chain (reference src/twoDtwoD.py:57-79): E = K^T F K -> decomposeEssentialMatrix ->
+        # disambiguateRelativePose over the F inliers, on the device, on the caller's stream right behind the F-RANSAC
+        res.tail = pipeline.pose_tail(res, ps.K)
     if prefetch:
         ps.prepared[1] = pipeline.prepare_descriptors(ps.q, ps.t, reuse=ps.prepared[1])     # for the next step
         ps.prepared.reverse()
@@ -290,6 +294,8 @@ def worker(args) -> int:
     from visual_odometry_amd import _lib, ops, parallel
 
     cfg = dict(CONFIGS[args.config])
+    if args.no_pnp:
+        cfg["p_iters"] = 0                                    # A/B only: prices what the PnP side stream costs the F chain
     B = args.pairs or cfg["pairs"]
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", str(_free_port()))
@@ -312,7 +318,7 @@ def worker(args) -> int:
     ps = PairSet(cfg, B, dev, 0 if shard else 1000 * rank)
     lib = _lib.load()
     for _ in range(args.warmup):
-        step(ps, cfg, group, prefetch)
+        step(ps, cfg, group, prefetch, not args.no_pose_tail)
     torch.cuda.synchronize()
     # HIP events around single launches inside the entry points (the scoring kernels of both RANSAC
     # runs and the kNN sweep kernel), recorded on the stream those kernels run on
@@ -322,7 +328,7 @@ def worker(args) -> int:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step(ps, cfg, group, prefetch)
+        res = step(ps, cfg, group, prefetch, not args.no_pose_tail)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -348,7 +354,8 @@ def worker(args) -> int:
     # ---- what this rank's launches processed, counted outside the timed region from the last step's outputs
     NQ, NT, HF, HP = cfg["nq"], cfg["nt"], cfg["f_iters"], cfg["p_iters"]
     n_match = res.n_match.cpu().numpy().astype(np.int64)
-    res_f, res_p = res.f_result.cpu().numpy(), res.p_result.cpu().numpy()
+    res_f = res.f_result.cpu().numpy()
+    res_p = res.p_result.cpu().numpy() if res.p_result is not None else np.zeros((B, 4), np.int32)
     # shard mode: this rank scores its slice of every F problem's iterations and whole PnP problems of its pairs
     h_f = parallel.shard_bounds(HF, rank, world) if shard else (0, HF)
     p_pairs = range(*parallel.shard_bounds(B, rank, world)) if shard else range(B)
@@ -356,11 +363,11 @@ def worker(args) -> int:
     for b in range(B):
         n = int(n_match[b])
         nm_f.append(ops.solve_7pt(res.f_samples[b, h_f[0]:h_f[1]], res.pts4[b, :n])[1].cpu().numpy())
-    for b in p_pairs:
+    for b in (p_pairs if HP > 0 else []):
         n = int(n_match[b])
         nm_p.append(ops.solve_p3p(res.p_samples[b], res.obj[b, :n], res.img[b, :n], ps.K)[2].cpu().numpy())
     mf = [int(x.sum()) for x in nm_f] if shard else models_scored(nm_f, res_f, HF, 0)
-    mp = models_scored(nm_p, res_p[list(p_pairs)], HP, FIRST_BLOCK)
+    mp = models_scored(nm_p, res_p[list(p_pairs)], HP, FIRST_BLOCK) if HP > 0 else []
     evals_f = int(sum(m * n for m, n in zip(mf, n_match)))
     evals_p = int(sum(m * n for m, n in zip(mp, n_match[list(p_pairs)])))
     n_models_f, n_models_p = int(sum(mf)), int(sum(mp))
@@ -446,6 +453,9 @@ def worker(args) -> int:
                   f"P3P PnP-RANSAC with maxIters {HP} over them with 55 % of the landmarks replaced by unrelated points "
                   f"(OpenCV's adaptive loop runs a few hundred iterations; blocks of 64, 320, 1600, ... are scored) + EPnP refit, "
                   f"and the {HF}-iteration 7-point F-RANSAC, per frame pair"}[args.config]
+    wl += ("; both chains end at a pose: the 2D-2D chain goes on through E = K^T F K, decomposeEssentialMatrix and "
+           "disambiguateRelativePose over the F inliers (device pose tail, R,t + triangulated points out), the 3D-2D chain ends "
+           "with the EPnP refit" if not args.no_pose_tail else "; the 2D-2D chain stops at F (--no-pose-tail)")
     par_note = (f"ONE batch of {B} pairs over {world} GPU(s): query rows split for the match (all_gather of the 2-NN rows), "
                 "F-RANSAC iteration ranges split over the ranks (all_gather of count tables + all-reduce of winners, replicated replay), "
                 "PnP problems dealt to the ranks by pair (all_gather of the packed results)"
@@ -459,7 +469,7 @@ def worker(args) -> int:
         "data_note": "every frame pair of a step is a different synthetic scene (4 from the host generator -- the ones the CPU "
                      "baseline runs -- the rest from the device generator of the same recipe); random-init, no dataset",
         "config": {"workload": wl, "pairs_per_step": B if shard else B * world, "pairs_per_gpu_per_step": None if shard else B,
-                   "mode": args.mode, "descriptor_prefetch": prefetch, "parallelism": par_note, "process_group": f"nccl (RCCL), world size {world}"},
+                   "mode": args.mode, "pose_tail_in_step": not args.no_pose_tail, "descriptor_prefetch": prefetch, "parallelism": par_note, "process_group": f"nccl (RCCL), world size {world}"},
         "ransac_scoring": {"metric": "RANSAC hypotheses x points scored/sec",
                            "value": evals_f / t_f,
                            "unit": "evaluations/s per GPU inside the F scoring kernel (models that exist x correspondences)",
@@ -497,6 +507,9 @@ def main() -> int:
     ap.add_argument("--prefetch", action="store_true",
                     help="weak mode: convert the next step's descriptors underneath this step's scoring (pipeline.prepare_descriptors; "
                          "measured neutral: 9.17 vs 9.16 ms per step, DESIGN.md section 7)")
+    ap.add_argument("--no-pose-tail", action="store_true",
+                    help="end the 2D-2D chain at F (round-2 workload) instead of at the relative pose (A/B of the pose tail's cost)")
+    ap.add_argument("--no-pnp", action="store_true", help="A/B only: drop the PnP chain (side stream) from the step")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the single-pair drop_in_latency leg (profiling runs: keeps rocprofv3's per-kernel "

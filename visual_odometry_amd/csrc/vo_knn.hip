@@ -47,9 +47,6 @@
 #ifndef VO_KNN_XCD
 #define VO_KNN_XCD 1         /* problems of a batch are pinned to XCDs (shared L2 for the train rows of a problem) */
 #endif
-#ifndef VO_ABLATE
-#define VO_ABLATE 0      /* 1, 2: timing experiments only (scripts/knn_ablate.sh), results are wrong */
-#endif
 
 namespace {
 
@@ -240,10 +237,6 @@ void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict_
     // of {m1, m2, p0, p1} are max3(m1, p0, p1) and max(m2, med3(m1, p0, p1)): 2.5 VALU ops per element
     // (key build included)
     auto epilogue = [&](const v16i& acc, const v4i* cv, int set) {
-#if VO_ABLATE == 1          /* experiment: no top-2 epilogue */
-        asm volatile("" :: "v"(acc));
-        m1[set][0] = max(m1[set][0], cv[0][0] + cv[1][1] + cv[2][2] + cv[3][3]);
-#else
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const int p0 = (acc[r] << 9) + cv[r >> 2][r & 3];
@@ -252,7 +245,6 @@ void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict_
             m2[set][c] = max(m2[set][c], med3i(m1[set][c], p0, p1));
             m1[set][c] = max3i_op(m1[set][c], p0, p1);
         }
-#endif
     };
 
     if (nchunks > 0) {
@@ -264,7 +256,7 @@ void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict_
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int buf = chunk & 1;
-        if (VO_ABLATE != 4 && VO_ABLATE != 5 && chunk + 1 < nchunks) stage_rows(chunk + 1, buf ^ 1);   // DMA runs under the sweep below
+        if (chunk + 1 < nchunks) stage_rows(chunk + 1, buf ^ 1);   // DMA runs under the sweep below
 
         const char* base = smem + buf * kBufBytes;
         const int* cbase = (const int*)(base + kChunkRows * kDim);
@@ -317,32 +309,25 @@ void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict_
         for (int tile = 0; tile < kChunkTiles; ++tile) {
             v4i va[4], cv[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) va[s] = *(const v4i*)(fbase + (VO_ABLATE == 3 ? 0 : tile) * kTileRows * kDim + foff[s]);
+            for (int s = 0; s < 4; ++s) va[s] = *(const v4i*)(fbase + tile * kTileRows * kDim + foff[s]);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) cv[g] = *(const v4i*)(cbase + (VO_ABLATE == 3 ? 0 : tile) * kTileRows + 8 * g + 4 * h);
+            for (int g = 0; g < 4; ++g) cv[g] = *(const v4i*)(cbase + tile * kTileRows + 8 * g + 4 * h);
 #pragma unroll
             for (int set = 0; set < kSets; ++set) {
                 v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#if VO_ABLATE == 2          /* experiment: no MFMA */
-#pragma unroll
-                for (int s = 0; s < 4; ++s) { acc[4 * s] = va[s][0] ^ qb[set][s][0]; acc[4 * s + 1] = va[s][1]; acc[4 * s + 2] = va[s][2]; acc[4 * s + 3] = va[s][3]; }
-#else
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
                     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(va[s], qb[set][s], acc, 0, 0, 0);
-#endif
                 epilogue(acc, cv, set);
             }
         }
 
 #endif
-        if (VO_ABLATE != 4 && VO_ABLATE != 5 && chunk + 1 < nchunks) stage_c(chunk + 1, buf ^ 1);
+        if (chunk + 1 < nchunks) stage_c(chunk + 1, buf ^ 1);
         if (((chunk + 1) & (kSegTiles / kChunkTiles - 1)) == 0 || chunk + 1 == nchunks)
             fold(row0 + (chunk / (kSegTiles / kChunkTiles)) * (kSegTiles * kTileRows));
-        if (VO_ABLATE != 5) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
 
     // ---- the two lane halves hold the same query over interleaved train rows: merge

@@ -36,11 +36,6 @@
 #ifndef VO_SCORE_CONST_LDS
 #define VO_SCORE_CONST_LDS 1          // 1: tier 1b reads the models' f32 filter constants from LDS (12 KB) instead of lane shuffles
 #endif
-#ifndef VO_SCORE_ABLATE
-#define VO_SCORE_ABLATE 0             // timing builds with WRONG counts (scripts/diag/ab_libs.sh): 1 = ragged tails never reach tier 2;
-                                      // 3 = tier 1a alone; 4 = + queue building; 5 = + tier 1b, nothing reaches tier 2;
-                                      // 8 = PnP / E: the f32 filter alone (its exact tier is 0.1 of PnP's 1.2 ms standalone)
-#endif
 
 namespace {
 
@@ -696,9 +691,7 @@ void score_kernel(const ScoreArgs a)
                     if (has[j]) {
                         const int m = ent[j] >> 9;
                         if (verdict[j] > 0) atomicAdd(&wcnt[w][m], 1);
-#if VO_SCORE_ABLATE != 5               // timing experiment: pooled tier 1b, nothing queued for tier 2
                         else if (verdict[j] == 0) wq2[w][atomicAdd(&wq2n[w], 1u)] = (uint16_t)ent[j];
-#endif
                     }
                 }
 #ifdef VO_SCORE_STATS
@@ -739,9 +732,6 @@ void score_kernel(const ScoreArgs a)
                 unsigned long long und = 0;
                 if (force) { cand = 0; und = ~0ull; }          // model or threshold outside the f32 filter's domain: all to tier 2
                 if (!live) { cand = 0; und = 0; }
-#if VO_SCORE_ABLATE == 3               // timing experiments only (wrong counts): tier 1a alone
-                cnt += __popcll(cand); cand = 0; und = 0;
-#endif
                 uint32_t at = atomicAdd(&wtot[w], (uint32_t)__popcll(cand));           // this lane's place in the queue
                 wave_sync();
                 const uint32_t q1new = __builtin_amdgcn_readfirstlane(lds_load(&wtot[w]));
@@ -758,9 +748,6 @@ void score_kernel(const ScoreArgs a)
                     }
                     q1 = q1new;
                     wave_sync();
-#if VO_SCORE_ABLATE == 4               // ... + list building
-                    cnt += at; q1 = 0;
-#endif
                     if (q1 >= (uint32_t)kBatch) {
                         do {
                             q1 -= kBatch;
@@ -771,10 +758,6 @@ void score_kernel(const ScoreArgs a)
                         if (lane == 0) wtot[w] = q1;
                         wave_sync();
                     }
-#if VO_SCORE_ABLATE == 4
-                    if (lane == 0) wtot[w] = 0;
-                    wave_sync();
-#endif
                 } else {
                     // more survivors in one block than the queue has room for: the owners take them, one per lane per trip
                     wave_sync();
@@ -831,9 +814,6 @@ void score_kernel(const ScoreArgs a)
                 for (int k = 0; k < nb; ++k) tier1(k);
             }
             if (!live) bits = 0;
-#if VO_SCORE_ABLATE == 1               // timing experiment only (wrong near the threshold)
-            bits = 0;
-#endif
             own_tier2(bits, i0, nb);
         }
     } else if (KIND == kPnp) {
@@ -864,9 +844,6 @@ void score_kernel(const ScoreArgs a)
                 uint32_t bits = ~(in_bits | out_bits) | force;
                 cnt += __popc(in_bits & ~force);
                 if (!live) bits = 0;
-#if VO_SCORE_ABLATE == 8               // timing experiment (wrong counts): PnP / E filter alone
-                cnt += __popc(bits); bits = 0;
-#endif
                 // tier 2: the exact evaluation for what the filter could not decide, one entry per lane per trip
                 while (__any(bits != 0)) {
                     if (bits) {
@@ -905,9 +882,6 @@ void score_kernel(const ScoreArgs a)
                 uint32_t bits = ~(in_bits | out_bits) | force;
                 cnt += __popc(in_bits & ~force);
                 if (!live) bits = 0;
-#if VO_SCORE_ABLATE == 8               // timing experiment (wrong counts): PnP / E filter alone
-                cnt += __popc(bits); bits = 0;
-#endif
                 // tier 2: the exact evaluation for what the filter could not decide, one entry per lane per trip
                 while (__any(bits != 0)) {
                     if (bits) {
