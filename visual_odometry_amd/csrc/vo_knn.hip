@@ -30,13 +30,7 @@
 #define VO_KNN_WAVES 8       /* waves per workgroup */
 #endif
 #ifndef VO_KNN_TILES
-#define VO_KNN_TILES 4       /* 32-row train tiles per LDS stage */
-#endif
-#ifndef VO_KNN_PIPE
-#define VO_KNN_PIPE 0        /* 1: MFMAs of the next tile issued ahead of the current tile's epilogue (measured: no gain) */
-#endif
-#ifndef VO_KNN_CHAINS
-#define VO_KNN_CHAINS 2      /* independent top-2 lists per query set in the epilogue (1, 2 or 4) */
+#define VO_KNN_TILES 6       /* 32-row train tiles per LDS stage */
 #endif
 #ifndef VO_KNN_MINW
 #define VO_KNN_MINW 2        /* waves per SIMD the register allocation must allow */
@@ -54,9 +48,10 @@ constexpr int kDim = VO_DESC_DIM;
 constexpr int kTileRows = 32;
 constexpr int kChunkTiles = VO_KNN_TILES;
 constexpr int kChunkRows = kTileRows * kChunkTiles;          // 128 train rows per LDS stage
-constexpr int kSegTiles = 16;                                 // tile index bits in the key
+constexpr int kSegChunks = 2;                                 // chunks per key segment (a power of two)
+constexpr int kSegTiles = kSegChunks * kChunkTiles;           // tiles whose index fits the key's 4 tile bits
+static_assert(kSegTiles <= 16, "tile index must fit 4 bits of the packed key");
 constexpr int kSets = VO_KNN_SETS;                                      // 32-query sets per wave
-constexpr int kChains = VO_KNN_CHAINS;
 constexpr int kWaveQ = 32 * kSets;                            // query rows per wave
 constexpr int kWgWaves = VO_KNN_WAVES;
 constexpr int kWgQ = kWaveQ * kWgWaves;                       // 256 query rows per workgroup
@@ -190,35 +185,36 @@ void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict_
             stage_piece(t, base + piece * 1024, piece * 8, rbase + piece * 8, row_end, lane);
         }
     };
-    auto stage_c = [&](int chunk, int buf) {
-        if (tid >= kChunkRows) return;
+    // the norm of row tid of a chunk is fetched at the START of the previous chunk's sweep (stage_c_load) and turned
+    // into the key constant at its end (stage_c_store): the load's latency is not waited for
+    auto stage_c_load = [&](int chunk) -> int {
+        if (tid >= kChunkRows) return 0;
         const int gr = row0 + chunk * kChunkRows + tid;
-        const int tn = tnorm[min(gr, row_end - 1)];
-        const int tile16 = ((gr - row0) >> 5) & (kSegTiles - 1);
+        return tnorm[min(gr, row_end - 1)];
+    };
+    auto stage_c_store = [&](int chunk, int buf, int tn) {
+        if (tid >= kChunkRows) return;
+        asm volatile("" : "+v"(tn));                 // keeps the arithmetic (and with it the wait for the load) down here
+        const int gr = row0 + chunk * kChunkRows + tid;
+        const int tile16 = ((gr - row0) >> 5) % kSegTiles;
         const int i = tid & 31, slot = (i & 3) | ((i >> 3) << 2);
         const int c = gr < row_end ? (-tn) * 256 + ((15 - tile16) << 4) + (15 - slot) : INT_MIN;
         ((int*)(smem + buf * kBufBytes + kChunkRows * kDim))[tid] = c;
     };
-
     Top2 run[kSets];
 #pragma unroll
     for (int set = 0; set < kSets; ++set) { run[set].k1 = run[set].k2 = INT_MIN; run[set].j1 = run[set].j2 = -1; }
-    int m1[kSets][kChains], m2[kSets][kChains];  // [set][chain] packed running top-2 of the current segment
+    // packed running top-2 of the current key segment: two m1 chains per query set and their common m2
+    int m1[kSets][2], m2[kSets];
 #pragma unroll
-    for (int set = 0; set < kSets; ++set)
-#pragma unroll
-        for (int c = 0; c < kChains; ++c) m1[set][c] = m2[set][c] = INT_MIN;
+    for (int set = 0; set < kSets; ++set) m1[set][0] = m1[set][1] = m2[set] = INT_MIN;
 
     auto fold = [&](int seg_row_base) {
 #pragma unroll
         for (int set = 0; set < kSets; ++set) {
-            int n1 = m1[set][0], n2 = m2[set][0];
-#pragma unroll
-            for (int c = 1; c < kChains; ++c) {
-                const int b1 = m1[set][c], b2 = m2[set][c];
-                n2 = max3i(min(n1, b1), n2, b2);
-                n1 = max(n1, b1);
-            }
+            // the two largest of the union: max of the chain maxima, then the larger of the other chain's maximum and m2
+            const int n1 = max(m1[set][0], m1[set][1]);
+            const int n2 = max(min(m1[set][0], m1[set][1]), m2[set]);
             const int pv[2] = {n1, n2};
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -228,35 +224,59 @@ void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict_
                 const int j = p == INT_MIN ? -1 : seg_row_base + tile16 * kTileRows + i;
                 insert_later(run[set], p >> 8, j);
             }
-#pragma unroll
-            for (int c = 0; c < kChains; ++c) m1[set][c] = m2[set][c] = INT_MIN;
+            m1[set][0] = m1[set][1] = m2[set] = INT_MIN;
         }
     };
 
-    // top-2 update of one 32x32 tile of dot products, two keys at a time: with m1 >= m2 the two largest
-    // of {m1, m2, p0, p1} are max3(m1, p0, p1) and max(m2, med3(m1, p0, p1)): 2.5 VALU ops per element
-    // (key build included)
-    auto epilogue = [&](const v16i& acc, const v4i* cv, int set) {
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const int p0 = (acc[r] << 9) + cv[r >> 2][r & 3];
-            const int p1 = (acc[r + 1] << 9) + cv[r >> 2][(r & 3) + 1];
-            const int c = (r >> 1) & (kChains - 1);
-            m2[set][c] = max(m2[set][c], med3i(m1[set][c], p0, p1));
-            m1[set][c] = max3i_op(m1[set][c], p0, p1);
-        }
+    // Top-2 update of a quarter of one 32x32 tile of dot products (accumulator registers 4s .. 4s+3 = four train rows
+    // of the lane's query), two keys at a time: with m1 >= m2 the two largest of {m1, m2, p0, p1} are
+    // max3(m1, p0, p1) and max(m2, med3(m1, p0, p1)).  The two pairs of a quarter go to two independent m1 chains
+    // (their instructions alternate, so no instruction waits for the one just issued) and share one m2 = the maximum
+    // of every med3 so far: 4 key builds + 2 med3 + 2 max3 + 1 max3 = 9 VALU instructions per four rows.
+    auto epilogue_part = [&](const v16i& acc, const v4i& c4, int set, int s) {
+        const int p0 = (acc[4 * s] << 9) + c4[0], p1 = (acc[4 * s + 1] << 9) + c4[1];
+        const int p2 = (acc[4 * s + 2] << 9) + c4[2], p3 = (acc[4 * s + 3] << 9) + c4[3];
+        asm volatile("" :: "v"(p0), "v"(p1), "v"(p2), "v"(p3));      // all four keys before the first selection
+        const int t0 = med3i(m1[set][0], p0, p1);
+        const int t1 = med3i(m1[set][1], p2, p3);
+        m1[set][0] = max3i_op(m1[set][0], p0, p1);
+        m1[set][1] = max3i_op(m1[set][1], p2, p3);
+        m2[set] = max3i(m2[set], t0, t1);
     };
 
     if (nchunks > 0) {
         stage_rows(0, 0);
-        stage_c(0, 0);
+        stage_c_store(0, 0, stage_c_load(0));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // Software pipeline inside the wave, one MFMA at a time and one unit deep, running ACROSS the chunk barriers.
+    // A unit is one (32-row tile, 32-query set) pair = four dependent MFMAs.  Block j of a chunk issues the four MFMAs
+    // of unit j with a quarter of the top-2 epilogue of unit j-2 (8-9 VALU instructions) behind each of them: the VALU
+    // work issues while the matrix pipe is busy (an MFMA holds the SIMD's vector issue for 8 of its 32 cycles; issued as
+    // a block of four, a wave sits in MFMA issue for ~100 cycles and only the last one overlaps anything), and the
+    // accumulators it reads were finished a whole block ago, so no hazard wait states separate MFMA and reader (with
+    // the epilogue only one MFMA behind its tile the compiler has to pad 40-cycle s_nops, measured: no gain at all).
+    // Three accumulator sets rotate (unit j -> set j % 3; kUnits is a multiple of 3, so the rotation is static); the
+    // last two units of a chunk are finished under the first two MFMA groups of the next chunk, after the barrier.
+    // A fragments of tile k+1 and key constants of tile k are read from LDS while tile k is being multiplied.
+    constexpr int kUnits = kChunkTiles * kSets;
+    static_assert(kSets == 2 && kUnits % 3 == 0, "the accumulator rotation below assumes 2 query sets and 3 | units per chunk");
+    const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const v4i none4 = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+    v16i accb[3] = {zero16, zero16, zero16};
+    v4i va[2][4], cv[2][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) cv[(kChunkTiles - 1) & 1][g] = none4;     // "units -2, -1": keys INT_MIN, never selected
+
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int buf = chunk & 1;
-        if (chunk + 1 < nchunks) stage_rows(chunk + 1, buf ^ 1);   // DMA runs under the sweep below
+        int tn_next = 0;
+        if (chunk + 1 < nchunks) {
+            stage_rows(chunk + 1, buf ^ 1);                        // DMA runs under the sweep below
+            tn_next = stage_c_load(chunk + 1);
+        }
 
         const char* base = smem + buf * kBufBytes;
         const int* cbase = (const int*)(base + kChunkRows * kDim);
@@ -264,70 +284,49 @@ void knn2_partial_kernel(const int8_t* __restrict__ q, const int8_t* __restrict_
         int foff[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) foff[s] = ((2 * s + h) ^ ((qrow >> 1) & 7)) << 4;
-
-#if VO_KNN_PIPE
-        // Software pipeline inside the wave: the four MFMAs of unit u+1 (a 32x32 tile of one query set)
-        // are issued BEFORE the top-2 epilogue of unit u, whose VALU work then runs while the matrix
-        // pipe is busy.  The register allocation leaves two waves per SIMD, both of this workgroup and
-        // nearly in phase, so overlap across waves alone does not happen.
-        {
-            constexpr int kUnits = kChunkTiles * kSets;
-            v4i va[4], cvb[2][4];
-            v16i accb[2];
-            auto load_tile = [&](int tile, int slot) {
+        auto load_va = [&](int tile) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) va[s] = *(const v4i*)(fbase + tile * kTileRows * kDim + foff[s]);
+            for (int s = 0; s < 4; ++s) va[tile & 1][s] = *(const v4i*)(fbase + tile * kTileRows * kDim + foff[s]);
+        };
+        auto load_cv = [&](int tile) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) cvb[slot][g] = *(const v4i*)(cbase + tile * kTileRows + 8 * g + 4 * h);
-            };
-            auto issue = [&](int set, int slot) {
-                v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int g = 0; g < 4; ++g) cv[tile & 1][g] = *(const v4i*)(cbase + tile * kTileRows + 8 * g + 4 * h);
+        };
+        load_va(0);
+        __builtin_amdgcn_sched_barrier(0);                 // tile 0's fragments first: the first MFMA waits for them only
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(va[s], qb[set][s], acc, 0, 0, 0);
-                accb[slot] = acc;
-            };
-            load_tile(0, 0);
-            issue(0, 0);
+        for (int j = 0; j < kUnits; ++j) {
+            const int tile = j / kSets, set = j % kSets;
+            // unit j-2: same query set, previous tile (for j = 0, 1 the last tile of the previous chunk)
+            const int ptile = (tile + kChunkTiles - 1) % kChunkTiles;
+            if (set == 0) {
+                if (tile + 1 < kChunkTiles) load_va(tile + 1);
+                load_cv(tile);                              // used from block j+2 on; its register set is free: cv(tile-2) is done
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < kUnits; ++u) {
-                const int tile = u / kSets, set = u % kSets;
-                if (u + 1 < kUnits) {
-                    const int ntile = (u + 1) / kSets, nset = (u + 1) % kSets;
-                    if (nset == 0) load_tile(ntile, ntile & 1);
-                    issue(nset, (u + 1) & 1);
-                }
+            for (int s = 0; s < 4; ++s) {
+                accb[j % 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(va[tile & 1][s], qb[set][s], s == 0 ? zero16 : accb[j % 3], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                epilogue(accb[u & 1], cvb[tile & 1], set);
+                epilogue_part(accb[(j + 1) % 3], cv[ptile & 1][s], set, s);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
-#else
-        // no software pipelining: 4 waves per SIMD (two 8-wave workgroups per CU) cover the MFMA
-        // chain latency and the LDS reads of one wave with the top-2 VALU work of the others
-#pragma unroll
-        for (int tile = 0; tile < kChunkTiles; ++tile) {
-            v4i va[4], cv[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) va[s] = *(const v4i*)(fbase + tile * kTileRows * kDim + foff[s]);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) cv[g] = *(const v4i*)(cbase + tile * kTileRows + 8 * g + 4 * h);
-#pragma unroll
-            for (int set = 0; set < kSets; ++set) {
-                v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(va[s], qb[set][s], acc, 0, 0, 0);
-                epilogue(acc, cv, set);
-            }
+            // the previous chunk closed a key segment: its last two units have just been folded into m1/m2
+            if (j == kSets - 1 && chunk > 0 && (chunk & (kSegChunks - 1)) == 0)
+                fold(row0 + (chunk / kSegChunks - 1) * (kSegTiles * kTileRows));
         }
 
-#endif
-        if (chunk + 1 < nchunks) stage_c(chunk + 1, buf ^ 1);
-        if (((chunk + 1) & (kSegTiles / kChunkTiles - 1)) == 0 || chunk + 1 == nchunks)
-            fold(row0 + (chunk / (kSegTiles / kChunkTiles)) * (kSegTiles * kTileRows));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (chunk + 1 < nchunks) stage_c_store(chunk + 1, buf ^ 1, tn_next);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
+    }
+    if (nchunks > 0) {
+        // drain: the last two units of the last chunk, then the open segment
+#pragma unroll
+        for (int j = kUnits; j < kUnits + kSets; ++j)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) epilogue_part(accb[(j + 1) % 3], cv[(kChunkTiles - 1) & 1][s], j % kSets, s);
+        fold(row0 + ((nchunks - 1) / kSegChunks) * (kSegTiles * kTileRows));
     }
 
     // ---- the two lane halves hold the same query over interleaved train rows: merge
