@@ -174,8 +174,10 @@ def step(ps: PairSet, cfg, group, prefetch: bool = False, pose_tail: bool = True
                                     first_block_pnp=FIRST_BLOCK, workspace=ps.ws, wait_pnp=False, group=group, prepared=prepared)
     if pose_tail:
         # "R,t out" of the 2D-2D chain (reference src/twoDtwoD.py:57-79): E = K^T F K -> decomposeEssentialMatrix ->
-        # disambiguateRelativePose over the F inliers, on the device, on the caller's stream right behind the F-RANSAC
-        res.tail = pipeline.pose_tail(res, ps.K)
+        # disambiguateRelativePose over the F inliers, on the device, behind the F-RANSAC.  Weak mode: on a side stream
+        # that the step does not wait for (like the PnP chain: 9.40 vs 9.55 ms per step with it on the caller's stream);
+        # the timed region ends with a device-wide synchronize
+        res.tail = pipeline.pose_tail(res, ps.K, wait=group is not None)
     if prefetch:
         ps.prepared[1] = pipeline.prepare_descriptors(ps.q, ps.t, reuse=ps.prepared[1])     # for the next step
         ps.prepared.reverse()

@@ -1,7 +1,7 @@
 // Micro-benchmark (measurement aid, not product code): do v_mfma_i32_32x32x32_i8 and the integer VALU instructions of
 // the kNN top-2 epilogue (v_lshl_add_u32 / v_med3_i32 / v_max3_i32) execute side by side on one SIMD of gfx950?
 // Every wave stamps s_memtime around its loop; printed: shader cycles per loop iteration per wave (median over waves),
-// at 1 and 2 waves per SIMD (one workgroup per CU).  One iteration = 4 dependent MFMAs and/or 36 VALU instructions.
+// at 1 to 4 waves per SIMD (one workgroup per CU).  One iteration = 4 dependent MFMAs and/or 36 VALU instructions.
 // Build: hipcc --offload-arch=gfx950 -O3 scripts/ubench/coexec.hip -o scripts/ubench/coexec
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -29,7 +29,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
     }
 
 template <int MODE>
-__global__ __launch_bounds__(512) void k(long long* stamps, int* out, int iters, int seed)
+__global__ __launch_bounds__(1024) void k(long long* stamps, int* out, int iters, int seed)
 {
     v4i a = {seed, seed + 1, seed + 2, seed + 3}, b = {seed * 3, seed, 7, 9};
     v16i acc[3] = {{0}, {0}, {0}};
@@ -151,7 +151,7 @@ void run(const char* name, int threads, double iter_scale)
 
 int main()
 {
-    for (int threads : {256, 512}) {
+    for (int threads : {256, 512, 768, 1024}) {
         run<0>("4 dependent MFMA", threads, 1);
         run<1>("36 VALU (lshl_add/med3/max3)", threads, 1);
         run<2>("4 x (MFMA + 9 VALU), VALU independent of the MFMA", threads, 1);

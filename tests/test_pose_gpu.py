@@ -235,3 +235,28 @@ def test_pipeline_refined_pose_equals_pnp_drop_in(det_math, dev):
         assert ok and okd[b] == 1
         assert np.allclose(Rt[b, :9].reshape(3, 3), rodrigues_vector_to_matrix(rvec.ravel()), rtol=1e-6, atol=1e-8)
         assert np.allclose(Rt[b, 9:], tvec.ravel(), rtol=1e-6, atol=1e-8)
+
+
+def test_pose_tail_deferred_equals_waited(dev):
+    """pipeline.pose_tail(wait=False) (side stream, not waited for by the caller's stream; what bench.py times) gives the
+    bits of the waited call, also with a second batch enqueued behind it; ragged inlier densities (a pair without a
+    model, a pair whose matches are nearly all inliers) go through the per-chunk inlier gathering."""
+    B, nq, nt = 4, 2600, 2500
+    K = synth.K_KITTI
+    fps = [synth.frame_pair(nq, nt, seed=400 + b, K=K, size=synth.IMAGE_SIZE["kitti"]) for b in range(B)]
+    st = lambda k: _d(np.stack([f[k] for f in fps]), dev)
+    args = (st("q"), st("t"), st("kp_q"), st("kp_t"))
+    r = pipeline.match_and_ransac(*args, 0.8, 1.0, 0.999, 200)
+    r.f_mask[1, : int(r.n_match[1])] = 1                     # a dense pair: every match an "inlier"
+    r.f_result[2, 0] = -1                                    # a pair without a model -> identity, no points
+    want = pipeline.pose_tail(r, K, 50.0)
+    torch.cuda.synchronize()
+    got = pipeline.pose_tail(r, K, 50.0, wait=False)
+    r2 = pipeline.match_and_ransac(*args, 0.8, 1.0, 0.999, 200)       # more work behind it on the caller's stream
+    torch.cuda.current_stream().wait_event(got["done"])
+    torch.cuda.synchronize()
+    for k in ("cand", "score", "T", "X", "keep"):
+        assert np.array_equal(got[k].cpu().numpy(), want[k].cpu().numpy(), equal_nan=True), k
+    assert int(want["keep"][1].sum()) > 0 and int(want["keep"][2].sum()) == 0
+    assert np.array_equal(want["T"][2].cpu().numpy().reshape(4, 4), np.eye(4))
+    del r2

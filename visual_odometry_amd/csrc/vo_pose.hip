@@ -278,37 +278,66 @@ __device__ __forceinline__ void k_times_rt(const double* K, const double* M, dou
         }
 }
 
-// grid (chunks of 256 correspondences, pairs): cheirality score of the four candidates
-__global__ __launch_bounds__(256)
+// Both kernels below work on chunks of kTailChunk correspondences of one pair (grid: chunks x pairs).  Only the F
+// inliers (typically 15-40 % of the matches, scattered) are triangulated, so each workgroup first gathers the
+// indices of its chunk's inliers into LDS and then walks that list with full waves; a wave in which one lane in six
+// has work would cost as much as a full one (the Jacobi sweeps are wave-uniform loops).
+constexpr int kTailChunk = 2048, kTailThreads = 256;
+
+__device__ __forceinline__ int tail_gather_inliers(const TailArgs& a, int b, int n, int base, int* s_list, int* s_n)
+{
+    if (threadIdx.x == 0) *s_n = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < kTailChunk; k += kTailThreads) {
+        const int i = base + k;
+        if (i < n && a.mask[(size_t)b * a.N + i] != 0) s_list[atomicAdd(s_n, 1)] = i;     // order is irrelevant
+    }
+    __syncthreads();
+    return *s_n;
+}
+
+// cheirality score of the four candidates
+__global__ __launch_bounds__(kTailThreads)
 void tail_score_kernel(const TailArgs a)
 {
     __shared__ double sP[4][12], sM[4][12], sP1[12];
-    __shared__ int ssc[4];
-    const int b = blockIdx.y;
+    __shared__ int s_list[kTailChunk], s_n;
+    const int b = blockIdx.y, base = blockIdx.x * kTailChunk;
     const int n = a.n_dev ? min(a.n_dev[b], a.N) : a.N;
-    if ((int)(blockIdx.x * 256) >= n || !pair_has_model(a, b)) return;
+    if (base >= n || !pair_has_model(a, b)) return;
     if (threadIdx.x < 4) {
         const double* M = a.cand + ((size_t)b * 4 + threadIdx.x) * 12;
         for (int k = 0; k < 12; ++k) sM[threadIdx.x][k] = M[k];
         k_times_rt(a.K, M, sP[threadIdx.x]);
-        ssc[threadIdx.x] = 0;
     }
     if (threadIdx.x == 4)
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 4; ++j) sP1[i * 4 + j] = j < 3 ? a.K[i * 3 + j] : 0.;
-    __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool live = i < n && a.mask[(size_t)b * a.N + i] != 0;
-    if (!__any(live)) return;                  // no barrier below
-    const float4 v = a.pts4[(size_t)b * a.N + (i < a.N ? i : 0)];
-    int sc[4];
+    const int cnt = tail_gather_inliers(a, b, n, base, s_list, &s_n);      // barriers inside also publish sP / sM
+    // Candidates 2r and 2r+1 share the rotation and differ in the sign of t.  Negating t negates the fourth column
+    // of the DLT matrix exactly (every entry is a difference of products that all change sign), and the one-sided
+    // Jacobi iteration commutes with that sign flip bit for bit (rotation angles change sign with the affected inner
+    // products, every intermediate is the exact negative or the same number), so the null vector comes out as
+    // +-(X0, X1, X2, -X3): the dehomogenised point of (R, -t) is exactly minus that of (R, +t), and so is its depth in
+    // the second camera.  One triangulation therefore scores both candidates, with the same bits as two would.
+    int sc[4] = {0, 0, 0, 0};
+    for (int t0 = 0; t0 < cnt; t0 += kTailThreads) {
+        const int t = t0 + threadIdx.x;
+        const bool live = t < cnt;
+        if (!__any(live)) break;                // wave-uniform
+        const float4 v = a.pts4[(size_t)b * a.N + s_list[live ? t : 0]];
 #pragma unroll 1
-    for (int c = 0; c < 4; ++c) {
-        double X[4];
-        triangulate_one(sP1, sP[c], v.x, v.y, v.z, v.w, X);
-        const double x = X[0] / X[3], y = X[1] / X[3], z = X[2] / X[3], w = X[3] / X[3];
-        const double z2 = sM[c][8] * x + sM[c][9] * y + sM[c][10] * z + sM[c][11] * w;
-        sc[c] = live ? (int)(z > 0) + (int)(z2 > 0) : 0;
+        for (int r = 0; r < 2; ++r) {
+            const int c = 2 * r;
+            double X[4];
+            triangulate_one(sP1, sP[c], v.x, v.y, v.z, v.w, X);
+            const double x = X[0] / X[3], y = X[1] / X[3], z = X[2] / X[3], w = X[3] / X[3];
+            const double z2 = sM[c][8] * x + sM[c][9] * y + sM[c][10] * z + sM[c][11] * w;
+            if (live) {
+                sc[c] += (int)(z > 0) + (int)(z2 > 0);
+                sc[c + 1] += (int)(-z > 0) + (int)(-z2 > 0);
+            }
+        }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -318,12 +347,13 @@ void tail_score_kernel(const TailArgs a)
     }
 }
 
-// grid (chunks, pairs): first strict maximum wins; points of the winner, depth/distance mask, T
-__global__ __launch_bounds__(256)
+// first strict maximum wins; points of the winner, depth/distance mask, T
+__global__ __launch_bounds__(kTailThreads)
 void tail_final_kernel(const TailArgs a)
 {
     __shared__ double sP[12], sM[12], sP1[12];
-    const int b = blockIdx.y;
+    __shared__ int s_list[kTailChunk], s_n;
+    const int b = blockIdx.y, base = blockIdx.x * kTailChunk;
     const int n = a.n_dev ? min(a.n_dev[b], a.N) : a.N;
     const bool have = pair_has_model(a, b);
     int best = 0;
@@ -344,29 +374,35 @@ void tail_final_kernel(const TailArgs a)
             T[12] = T[13] = T[14] = 0.; T[15] = 1.;
         }
     }
-    __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool inb = i < a.N;
-    const bool live = have && i < n && a.mask[(size_t)b * a.N + i] != 0;
-    double X[4] = {0., 0., 0., 0.};
-    bool keep = false;
-    if (__any(live)) {
-        const float4 v = a.pts4[(size_t)b * a.N + (inb ? i : 0)];
+    // rows that are not inliers (or lie past the pair's count, or belong to a pair without a model): zeros
+    for (int k = threadIdx.x; k < kTailChunk; k += kTailThreads) {
+        const int i = base + k;
+        if (i < a.N && !(have && i < n && a.mask[(size_t)b * a.N + i] != 0)) {
+            double2* out = (double2*)(a.X + ((size_t)b * a.N + i) * 4);
+            out[0] = make_double2(0., 0.); out[1] = make_double2(0., 0.);
+            a.keep[(size_t)b * a.N + i] = 0;
+        }
+    }
+    if (!have) return;                                                        // block-uniform
+    const int cnt = tail_gather_inliers(a, b, n, base, s_list, &s_n);
+    for (int t0 = 0; t0 < cnt; t0 += kTailThreads) {
+        const int t = t0 + threadIdx.x;
+        const bool live = t < cnt;
+        if (!__any(live)) break;
+        const int i = s_list[live ? t : 0];
+        const float4 v = a.pts4[(size_t)b * a.N + i];
         double H[4];
         triangulate_one(sP1, sP, v.x, v.y, v.z, v.w, H);
         if (live) {
+            double X[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) X[k] = H[k] / H[3];
             const double min_depth = sM[10] < 0. ? sM[10] : 0.;          // min(0, T[2,2])
             const double nrm = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2] + X[3] * X[3]);
-            keep = X[2] > min_depth && nrm < a.max_depth;
+            double2* out = (double2*)(a.X + ((size_t)b * a.N + i) * 4);
+            out[0] = make_double2(X[0], X[1]); out[1] = make_double2(X[2], X[3]);
+            a.keep[(size_t)b * a.N + i] = X[2] > min_depth && nrm < a.max_depth;
         }
-    }
-    if (inb) {
-        double* out = a.X + ((size_t)b * a.N + i) * 4;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) out[k] = X[k];
-        a.keep[(size_t)b * a.N + i] = keep;
     }
 }
 
@@ -394,7 +430,7 @@ extern "C" int vo_pose_tail_batch(const double* F, const int32_t* result, const 
     if (batch == 0) return VO_OK;
     VO_CHECK_ARG(F && K_host && cand && score && T, VO_EINVAL, "vo_pose_tail_batch: null pointer");
     VO_CHECK_ARG(N == 0 || (mask && pts4 && X && keep), VO_EINVAL, "vo_pose_tail_batch: null point buffers");
-    VO_CHECK_ARG(((uintptr_t)pts4 & 15) == 0, VO_EINVAL, "vo_pose_tail_batch: pts4 must be 16-byte aligned");
+    VO_CHECK_ARG((((uintptr_t)pts4 | (uintptr_t)X) & 15) == 0, VO_EINVAL, "vo_pose_tail_batch: pts4 and X must be 16-byte aligned");
     VO_CHECK_ARG(batch <= 65535, VO_ESIZE, "vo_pose_tail_batch: batch too large");
     hipStream_t s = (hipStream_t)stream;
     TailArgs a;
@@ -403,12 +439,12 @@ extern "C" int vo_pose_tail_batch(const double* F, const int32_t* result, const 
     for (int k = 0; k < 9; ++k) a.K[k] = K_host[k];
     hipLaunchKernelGGL(tail_candidates_kernel, dim3(vo_ceil_div(batch, 64)), dim3(64), 0, s, a, batch);
     VO_LAUNCH_CHECK();
-    const dim3 grid(vo_ceil_div(N > 0 ? N : 1, 256), batch);
+    const dim3 grid(vo_ceil_div(N > 0 ? N : 1, kTailChunk), batch);
     if (N > 0) {
-        hipLaunchKernelGGL(tail_score_kernel, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(tail_score_kernel, grid, dim3(kTailThreads), 0, s, a);
         VO_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(tail_final_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(tail_final_kernel, grid, dim3(kTailThreads), 0, s, a);
     VO_LAUNCH_CHECK();
     return VO_OK;
 }

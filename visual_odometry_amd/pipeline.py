@@ -341,12 +341,30 @@ def finish_small_pairs(res: PairBatchResult, f_threshold: float, f_confidence: f
     return int(((n >= 7) & (n <= 14)).sum())
 
 
-def pose_tail(res: PairBatchResult, K, max_depth: Optional[float] = None):
+def pose_tail(res: PairBatchResult, K, max_depth: Optional[float] = None, wait: bool = True):
     """The 2D-2D pose tail of src/twoDtwoD.py:57-79 for every pair of `res`, on the device:
     E = K^T F K -> decomposeEssentialMatrix -> disambiguateRelativePose over the F inliers.
     -> dict(cand, score, T (B,4,4) = T_cami_camj, X (B,nq,4) points in camera-i coordinates, keep (B,nq) u8);
-    rows follow res.pts4 (matched correspondences, first n_match[b] used)."""
+    rows follow res.pts4 (matched correspondences, first n_match[b] used).
+
+    wait=False: the tail (f64 Jacobi SVDs, latency bound) runs on a side stream of the caller's stream and the
+    caller's stream does NOT wait for it -- like the PnP chain with wait_pnp=False it then runs underneath the next
+    batch's matching; the dict carries the event `done` (torch.cuda.current_stream().wait_event(tail["done"]))."""
     if max_depth is None:
         from .params import get_params
         max_depth = get_params().INIT_PARAMS.MAX_DEPTH_DISTANCE
-    return ops.pose_tail_batch(res.F, res.f_mask, res.pts4, K, max_depth, result=res.f_result, n_dev=res.n_match)
+    if wait:
+        return ops.pose_tail_batch(res.F, res.f_mask, res.pts4, K, max_depth, result=res.f_result, n_dev=res.n_match)
+    main = torch.cuda.current_stream()
+    side = _side_stream(res.F.device, main, "tail")
+    side.wait_stream(main)
+    ins = (res.F, res.f_mask, res.pts4, res.f_result, res.n_match)
+    for t in ins:
+        t.record_stream(side)
+    with torch.cuda.stream(side):
+        out = ops.pose_tail_batch(res.F, res.f_mask, res.pts4, K, max_depth, result=res.f_result, n_dev=res.n_match)
+        out["done"] = side.record_event()
+    for t in out.values():
+        if isinstance(t, torch.Tensor):
+            t.record_stream(main)
+    return out
