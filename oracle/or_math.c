@@ -389,7 +389,9 @@ int vo_or_solve_poly(const double* coeffs, int deg, double* re, double* im)
         double nr = pr * 1 - pi * 1, ni = pr * 1 + pi * 1;
         pr = nr; pi = ni;
     }
-    for (int iter = 0; iter < 1000; ++iter) {
+    /* cv::solvePoly's default cap (core.hpp: maxIters = 300), which five-point.cpp runs with [OCV]; the update almost
+     * never reaches an exact fixpoint, so all of them run */
+    for (int iter = 0; iter < 300; ++iter) {
         double maxdiff = 0;
         for (int i = 0; i < n; ++i) {
             double xr = re[i], xi = im[i];

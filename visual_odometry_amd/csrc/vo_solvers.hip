@@ -12,6 +12,7 @@
 // so dynamic indexing costs no scratch and no bank conflicts.
 #include "vo_common.h"
 #include "vo_detmath.h"
+#include "vo_fivept_gen.h"
 #include <float.h>
 
 namespace {
@@ -954,6 +955,10 @@ __device__ void z_mul(const double* a, int da, const double* b, int db, double* 
     for (int i = 0; i <= da; ++i) for (int j = 0; j <= db; ++j) r[i + j] += a[i] * b[j];
 }
 
+// cv::solvePoly's default iteration cap (core.hpp: maxIters = 300), which is what five-point.cpp runs with.  The
+// update almost never reaches an exact fixpoint, so in practice this many sweeps always run.
+constexpr int kSolvePolyIters = 300;
+
 // Durand-Kerner on ascending real coefficients; returns #roots
 __device__ int solve_poly(const double* coeffs, int deg, double* re, double* im)
 {
@@ -966,7 +971,7 @@ __device__ int solve_poly(const double* coeffs, int deg, double* re, double* im)
         const double nr = pr * 1 - pi * 1, ni = pr * 1 + pi * 1;
         pr = nr; pi = ni;
     }
-    for (int iter = 0; iter < 1000; ++iter) {
+    for (int iter = 0; iter < kSolvePolyIters; ++iter) {
         double maxdiff = 0;
         for (int i = 0; i < n; ++i) {
             const double xr = re[i], xi = im[i];
@@ -997,13 +1002,142 @@ __device__ int solve_poly(const double* coeffs, int deg, double* re, double* im)
     return n;
 }
 
+// The same iteration for a polynomial whose degree is exactly N (leading coefficient above DBL_EPSILON), roots in
+// registers, every index a compile-time constant; operation order as in solve_poly, so the bits agree.  A lane that
+// has reached an exact fixpoint (or NaNs) rides along with the sweeps other lanes still need: its roots no longer change.
+template <int N>
+__device__ __forceinline__ void solve_poly_fixed(const double (&c)[N + 1], double (&re)[N], double (&im)[N])
+{
+    double pr = 1, pi = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        re[i] = pr; im[i] = pi;
+        const double nr = pr * 1 - pi * 1, ni = pr * 1 + pi * 1;
+        pr = nr; pi = ni;
+    }
+#pragma unroll 1
+    for (int iter = 0; iter < kSolvePolyIters; ++iter) {
+        double maxdiff = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double xr = re[i], xi = im[i];
+            double nr = c[N], ni = 0, dr = c[N], di = 0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                double tr = nr * xr - ni * xi + c[N - j - 1];
+                double ti = nr * xi + ni * xr;
+                nr = tr; ni = ti;
+                if (j != i) {
+                    const double er = xr - re[j], ei = xi - im[j];
+                    tr = dr * er - di * ei;
+                    ti = dr * ei + di * er;
+                    const bool distinct = er != 0 || ei != 0;
+                    dr = distinct ? tr : dr; di = distinct ? ti : di;
+                }
+            }
+            const double t = 1. / (dr * dr + di * di);
+            const double qr = (nr * dr + ni * di) * t, qi = (-nr * di + ni * dr) * t;
+            re[i] = xr - qr; im[i] = xi - qi;
+            const double ad = sqrt(qr * qr + qi * qi);
+            if (ad > maxdiff) maxdiff = ad;
+        }
+        if (!__any(maxdiff > 0)) break;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (fabs(im[i]) < 1e-100) im[i] = 0;
+}
+
+// Right singular vector of the smallest singular value of a 3 x 3 matrix: jacobi_svd<true>(At, 3, 3, 3) in registers
+// (rows of At = columns of the matrix), same pair order and operation order; returns the last row of V^T after the
+// descending sort.  The completion of degenerate left singular vectors is skipped: it never touches V.
+__device__ __forceinline__ void jacobi3_last_vt(double (&At)[3][3], double (&out)[3])
+{
+    const double eps = DBL_EPSILON * 10;
+    double W[3], Vt[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sd += At[i][k] * At[i][k];
+        W[i] = sd;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Vt[i][k] = i == k ? 1. : 0.;
+    }
+#pragma unroll 1
+    for (int iter = 0; iter < 30; ++iter) {
+        bool changed = false;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = i + 1; j < 3; ++j) {
+                double a = W[i], p = 0, b = W[j];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) p += At[i][k] * At[j][k];
+                if (!(fabs(p) <= eps * sqrt(a * b))) {
+                    p *= 2;
+                    const double beta = a - b, gamma = sqrt(p * p + beta * beta);
+                    double c, s;
+                    if (beta < 0) {
+                        const double delta = (gamma - beta) * 0.5;
+                        s = sqrt(delta / gamma);
+                        c = p / (gamma * s * 2);
+                    } else {
+                        c = sqrt((gamma + beta) / (gamma * 2));
+                        s = p / (gamma * c * 2);
+                    }
+                    a = b = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const double t0 = c * At[i][k] + s * At[j][k];
+                        const double t1 = -s * At[i][k] + c * At[j][k];
+                        At[i][k] = t0; At[j][k] = t1;
+                        a += t0 * t0; b += t1 * t1;
+                    }
+                    W[i] = a; W[j] = b;
+                    changed = true;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const double t0 = c * Vt[i][k] + s * Vt[j][k];
+                        const double t1 = -s * Vt[i][k] + c * Vt[j][k];
+                        Vt[i][k] = t0; Vt[j][k] = t1;
+                    }
+                }
+            }
+        if (!__any(changed)) break;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sd += At[i][k] * At[i][k];
+        W[i] = sqrt(sd);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int j = i;
+        double wj = W[i];
+#pragma unroll
+        for (int k = i + 1; k < 3; ++k)
+            if (wj < W[k]) { j = k; wj = W[k]; }
+#pragma unroll
+        for (int k = i + 1; k < 3; ++k)
+            if (j == k) {
+                double t = W[i]; W[i] = W[k]; W[k] = t;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) { t = Vt[i][e]; Vt[i][e] = Vt[k][e]; Vt[k][e] = t; }
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[k] = Vt[2][k];
+}
+
 __global__ __launch_bounds__(kLanes)
 void solve_5pt_kernel(const int32_t* __restrict__ samples, int H, const double* __restrict__ pts, int N,
                       double* __restrict__ models, int32_t* __restrict__ nmodels,
                       int per, int32_t* __restrict__ list, int32_t* __restrict__ nlist, const int32_t* __restrict__ n_dev,
                       int h0, int hlen, const int32_t* __restrict__ prev)
 {
-    __shared__ double lds[(81 + 9) * kLanes];
     // thread -> (problem b, iteration h0 + i) for the iteration block [h0, h0 + hlen) of every problem;
     // a problem whose sequential loop already ended (prev = its replay result, niters <= h0) is skipped
     const int tix = blockIdx.x * kLanes + threadIdx.x;
@@ -1015,57 +1149,35 @@ void solve_5pt_kernel(const int32_t* __restrict__ samples, int H, const double* 
     if (!__any(live)) return;
     const int nb_pts = n_dev ? min(n_dev[b], N) : N;
     pts += (size_t)b * N * 4;
-    const SV A9{lds + threadIdx.x}, W{lds + 81 * kLanes + threadIdx.x};
-    for (int k = 0; k < 81; ++k) A9[k] = 0;
-    for (int i = 0; i < 5; ++i) {
-        int idx = live ? samples[(size_t)h * 5 + i] : 0;
-        idx = max(min(idx, nb_pts - 1), 0);
-        const double x1 = pts[(size_t)idx * 4], y1 = pts[(size_t)idx * 4 + 1];
-        const double x2 = pts[(size_t)idx * 4 + 2], y2 = pts[(size_t)idx * 4 + 3];
-        const SV r = A9.at(9 * i);
-        r[0] = x2 * x1; r[1] = x2 * y1; r[2] = x2;
-        r[3] = y2 * x1; r[4] = y2 * y1; r[5] = y2;
-        r[6] = x1; r[7] = y1; r[8] = 1.0;
-    }
-    jacobi_svd<false>(A9, 9, 5, 9, W, SV{nullptr});
     double Nb[4][9];
-    for (int v = 0; v < 4; ++v)
-        for (int k = 0; k < 9; ++k) Nb[v][k] = A9[(5 + v) * 9 + k];
-
-    Poly Ep[3][3];
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
-        p_zero(Ep[r][c]);
-        Ep[r][c].c[kPolyIdx[1][0][0]] = Nb[0][3 * r + c];
-        Ep[r][c].c[kPolyIdx[0][1][0]] = Nb[1][3 * r + c];
-        Ep[r][c].c[kPolyIdx[0][0][1]] = Nb[2][3 * r + c];
-        Ep[r][c].c[kPolyIdx[0][0][0]] = Nb[3][3 * r + c];
-    }
-    Poly EEt[3][3], tr, tmp, tmp2;
-    p_zero(tr);
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
-        p_zero(EEt[r][c]);
-        for (int k = 0; k < 3; ++k) { p_mul(Ep[r][k], Ep[c][k], tmp); p_axpy(EEt[r][c], 1.0, tmp); }
-    }
-    for (int r = 0; r < 3; ++r) p_axpy(tr, 1.0, EEt[r][r]);
-
-    double A[10][20];
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
-        Poly acc; p_zero(acc);
-        for (int k = 0; k < 3; ++k) { p_mul(EEt[r][k], Ep[k][c], tmp); p_axpy(acc, 2.0, tmp); }
-        p_mul(tr, Ep[r][c], tmp);
-        p_axpy(acc, -1.0, tmp);
-        p_row(acc, A[3 * r + c]);
-    }
     {
-        Poly acc; p_zero(acc);
-        p_mul(Ep[1][1], Ep[2][2], tmp); p_mul(Ep[0][0], tmp, tmp2); p_axpy(acc, 1.0, tmp2);
-        p_mul(Ep[1][2], Ep[2][1], tmp); p_mul(Ep[0][0], tmp, tmp2); p_axpy(acc, -1.0, tmp2);
-        p_mul(Ep[1][0], Ep[2][2], tmp); p_mul(Ep[0][1], tmp, tmp2); p_axpy(acc, -1.0, tmp2);
-        p_mul(Ep[1][2], Ep[2][0], tmp); p_mul(Ep[0][1], tmp, tmp2); p_axpy(acc, 1.0, tmp2);
-        p_mul(Ep[1][0], Ep[2][1], tmp); p_mul(Ep[0][2], tmp, tmp2); p_axpy(acc, 1.0, tmp2);
-        p_mul(Ep[1][1], Ep[2][0], tmp); p_mul(Ep[0][2], tmp, tmp2); p_axpy(acc, -1.0, tmp2);
-        p_row(acc, A[9]);
+        // null space of the 5 x 9 epipolar system: the rows the Jacobi SVD completes the basis with (registers)
+        double A9[9][9], W9[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) A9[i][k] = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            int idx = live ? samples[(size_t)h * 5 + i] : 0;
+            idx = max(min(idx, nb_pts - 1), 0);
+            const double x1 = pts[(size_t)idx * 4], y1 = pts[(size_t)idx * 4 + 1];
+            const double x2 = pts[(size_t)idx * 4 + 2], y2 = pts[(size_t)idx * 4 + 3];
+            A9[i][0] = x2 * x1; A9[i][1] = x2 * y1; A9[i][2] = x2;
+            A9[i][3] = y2 * x1; A9[i][4] = y2 * y1; A9[i][5] = y2;
+            A9[i][6] = x1; A9[i][7] = y1; A9[i][8] = 1.0;
+        }
+        jacobi_rows_reg<9, 5, 9>(A9, W9);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Nb[v][k] = A9[5 + v][k];
     }
+
+    // the ten cubic constraints over the 20 monomials: generated straight-line code (vo_fivept_gen.h) in the operation
+    // order of the generic polynomial routines kept above for reference
+    double A[10][20];
+    fivept_constraints(Nb, A);
     bool singular = false;
     for (int col = 0; col < 10; ++col) {
         int piv = col;
@@ -1083,9 +1195,10 @@ void solve_5pt_kernel(const int32_t* __restrict__ samples, int H, const double* 
         }
     }
     int count = 0;
+    double B[3][3][5], cc[11];
+    for (int i = 0; i < 11; ++i) cc[i] = 0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) for (int k = 0; k < 5; ++k) B[i][j][k] = 0;
     if (!singular) {
-        double B[3][3][5];
-        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) for (int k = 0; k < 5; ++k) B[i][j][k] = 0;
         for (int i = 0; i < 3; ++i) {
             const double* ra = A[4 + 2 * i] + 10;
             const double* rb = A[5 + 2 * i] + 10;
@@ -1094,8 +1207,8 @@ void solve_5pt_kernel(const int32_t* __restrict__ samples, int H, const double* 
             B[i][2][0] = ra[9]; B[i][2][1] = ra[8] - rb[9]; B[i][2][2] = ra[7] - rb[8];
             B[i][2][3] = ra[6] - rb[7]; B[i][2][4] = -rb[6];
         }
-        double c[11], t1[8], t2[8], t3[12], m[8];
-        for (int i = 0; i < 11; ++i) c[i] = 0;
+        double t1[8], t2[8], t3[12], m[8];
+        double* const c = cc;
         z_mul(B[1][1], 3, B[2][2], 4, t1); z_mul(B[1][2], 4, B[2][1], 3, t2);
         for (int i = 0; i < 8; ++i) m[i] = t1[i] - t2[i];
         z_mul(B[0][0], 3, m, 7, t3);
@@ -1109,24 +1222,40 @@ void solve_5pt_kernel(const int32_t* __restrict__ samples, int H, const double* 
         z_mul(B[0][2], 4, m, 6, t3);
         for (int i = 0; i < 11; ++i) c[i] += t3[i];
 
-        double re[10], im[10];
-        const int nr = solve_poly(c, 10, re, im);
-        const SV At = A9, W3 = A9.at(9), Vt3 = A9.at(12);
-        for (int i = 0; i < nr && count < 10; ++i) {
-            if (fabs(im[i]) > 1e-10) continue;
+    }
+    // degree-10 polynomial in z: roots by Durand-Kerner.  All lanes of the wave take the register-resident form when
+    // every one of them has a full-degree polynomial (the normal case); otherwise the generic one.
+    double c[11], re[10], im[10];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) c[i] = singular ? (i == 10 ? 1. : 0.) : cc[i];
+    int nr = 10;
+    if (__all(fabs(c[10]) > DBL_EPSILON)) {
+        solve_poly_fixed<10>(c, re, im);
+    } else {
+        double cm[11], rm[10], imm[10];
+        for (int i = 0; i < 11; ++i) cm[i] = c[i];
+        nr = solve_poly(cm, 10, rm, imm);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) { re[i] = rm[i]; im[i] = imm[i]; }
+    }
+    if (!singular) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const bool real_root = i < nr && count < 10 && !(fabs(im[i]) > 1e-10);
+            if (!__any(real_root)) continue;                 // wave-uniform
             const double z1 = re[i], z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
-            double bz[9];
+            double At[3][3], v[3];
+#pragma unroll
             for (int j = 0; j < 3; ++j) {
-                bz[3 * j] = B[j][0][3] * z3 + B[j][0][2] * z2 + B[j][0][1] * z1 + B[j][0][0];
-                bz[3 * j + 1] = B[j][1][3] * z3 + B[j][1][2] * z2 + B[j][1][1] * z1 + B[j][1][0];
-                bz[3 * j + 2] = B[j][2][4] * z4 + B[j][2][3] * z3 + B[j][2][2] * z2 + B[j][2][1] * z1 + B[j][2][0];
+                At[0][j] = B[j][0][3] * z3 + B[j][0][2] * z2 + B[j][0][1] * z1 + B[j][0][0];
+                At[1][j] = B[j][1][3] * z3 + B[j][1][2] * z2 + B[j][1][1] * z1 + B[j][1][0];
+                At[2][j] = B[j][2][4] * z4 + B[j][2][3] * z3 + B[j][2][2] * z2 + B[j][2][1] * z1 + B[j][2][0];
             }
-            for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) At[cc * 3 + r] = bz[r * 3 + cc];
-            jacobi_svd<true>(At, 3, 3, 3, W3, Vt3);
-            const double v0 = Vt3[6], v1 = Vt3[7], v2 = Vt3[8];
-            if (fabs(v2) < 1e-10) continue;
-            const double x = v0 / v2, y = v1 / v2;
+            jacobi3_last_vt(At, v);
+            if (!real_root || fabs(v[2]) < 1e-10) continue;
+            const double x = v[0] / v[2], y = v[1] / v[2];
             double Ev[9], nrm = 0;
+#pragma unroll
             for (int k = 0; k < 9; ++k) {
                 Ev[k] = Nb[0][k] * x + Nb[1][k] * y + Nb[2][k] * z1 + Nb[3][k];
                 nrm += Ev[k] * Ev[k];
