@@ -57,6 +57,7 @@ CONFIGS = {
     "cfg5": dict(nq=32768, nt=32768, f_iters=4096, p_iters=65536, pairs=32, landmark_outliers=0.55),
 }
 
+PROFILE_TAG = "r3"            # profiles/<tag>_counters.json, <tag>_score_*_isa.json: what the roofline objects cite
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s HBM3E
 I8_OPS_PER_CLK_CU = 8192      # 4 SIMD x 2048 int8 ops/clk (v_mfma_i32_32x32x32_i8: 65536 ops / 32 clk)
 VALU_LANES_PER_CLK_CU = 128   # 4 SIMD-32: a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md)
@@ -156,7 +157,11 @@ class PairSet:
         self.prepared = [None, None]                            # descriptor prefetch buffers (step(prefetch=True))
 
 
-def step(ps: PairSet, cfg, group, prefetch: bool = False, pose_tail: bool = True):
+E_THR, E_CONF, E_MAX_ITERS = 1.0, 0.9999, 50000     # reference src/utils/geometry.py:43 defaults (1 px, 0.9999, 50000 iterations)
+E_SAMPLES = 4096              # getSubset samples evaluated per pair for the E chain (OpenCV's adaptive loop must end within them)
+
+
+def step(ps: PairSet, cfg, group, prefetch: bool = False, pose_tail: bool = True, ess: bool = False):
     """One pass over all pairs; everything is enqueued, nothing is read back.  Weak mode: main stream + the
     pipeline's PnP side stream (the PnP tail of one step may still be running when the next step starts; the
     timed region ends with a device-wide synchronize).  Shard mode: one stream, collectives inside.
@@ -169,6 +174,15 @@ def step(ps: PairSet, cfg, group, prefetch: bool = False, pose_tail: bool = True
         if ps.prepared[0] is None:                          # very first step: nothing was prefetched for it
             ps.prepared[0] = pipeline.prepare_descriptors(ps.q, ps.t)
         prepared = ps.prepared[0]
+    if ess:
+        # the essential-matrix form of the 2D-2D chain (reference src/utils/geometry.py:43-45, dormant there): five-point
+        # E-RANSAC with the reference's defaults instead of the 7-point F-RANSAC; the chain ends at (E, mask) as the
+        # reference's wrapper does
+        return pipeline.match_and_ransac(ps.q, ps.t, ps.kp_q, ps.kp_t, RATIO, F_THR, F_CONF, 0, xyz_q=ps.xyz_q,
+                                         K=ps.K, p_threshold=P_THR, p_confidence=P_CONF, p_iters=cfg["p_iters"],
+                                         first_block_pnp=FIRST_BLOCK, workspace=ps.ws, wait_pnp=False, prepared=prepared,
+                                         e_iters=E_SAMPLES, e_threshold=E_THR, e_confidence=E_CONF, e_max_iters=E_MAX_ITERS,
+                                         first_block_e=FIRST_BLOCK)
     res = pipeline.match_and_ransac(ps.q, ps.t, ps.kp_q, ps.kp_t, RATIO, F_THR, F_CONF, cfg["f_iters"], xyz_q=ps.xyz_q,
                                     K=ps.K, p_threshold=P_THR, p_confidence=P_CONF, p_iters=cfg["p_iters"],
                                     first_block_pnp=FIRST_BLOCK, workspace=ps.ws, wait_pnp=False, group=group, prepared=prepared)
@@ -222,7 +236,7 @@ def drop_in_latency(cfg):
     return out
 
 
-def cpu_baseline(cfg, max_seconds: float = 25.0):
+def cpu_baseline(cfg, max_seconds: float = 25.0, ess: bool = False):
     """The oracle (CPU restatement of the OpenCV routines; OpenCV itself is absent) on the same
     workload, a bounded number of frame pairs."""
     import numpy as np
@@ -243,7 +257,10 @@ def cpu_baseline(cfg, max_seconds: float = 25.0):
         qi, ti = np.nonzero(keep)[0], idx[keep, 0]
         p1, p2, xyz = fp["kp_q"][qi], fp["kp_t"][ti], fp["xyz_q"][qi]
         t1 = time.perf_counter()
-        oracle.find_fundamental_mat(p1, p2, F_THR, F_CONF, cfg["f_iters"])
+        if ess:
+            oracle.find_essential_mat(p1.astype(np.float64), p2.astype(np.float64), K, E_CONF, E_THR, E_MAX_ITERS)
+        else:
+            oracle.find_fundamental_mat(p1, p2, F_THR, F_CONF, cfg["f_iters"])
         t2 = time.perf_counter()
         oracle.solve_pnp_ransac(xyz, p2, K, cfg["p_iters"], P_THR, P_CONF)
         t3 = time.perf_counter()
@@ -252,7 +269,7 @@ def cpu_baseline(cfg, max_seconds: float = 25.0):
         done += 1
     return {"value": done / dt, "unit": "frame-pairs/s", "cores": threads, "kind": "port",
             "sample": f"{done} frame pairs of the same workload (match+gather {parts[0] / done * 1e3:.0f} ms on {threads} "
-                      f"OpenMP threads, F-RANSAC {parts[1] / done * 1e3:.0f} ms and PnP-RANSAC incl. EPnP refit "
+                      f"OpenMP threads, {'E' if ess else 'F'}-RANSAC {parts[1] / done * 1e3:.0f} ms and PnP-RANSAC incl. EPnP refit "
                       f"{parts[2] / done * 1e3:.0f} ms serial with OpenCV's adaptive early exit); CPU restatement of the "
                       f"OpenCV routines, not OpenCV"}
 
@@ -313,6 +330,10 @@ def worker(args) -> int:
     import datetime
     dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))   # RCCL, also with one rank
     shard = args.mode == "shard"
+    ess = args.ransac == "ess"
+    if ess and shard:
+        print("bench.py: --ransac ess runs in weak mode only", file=sys.stderr)
+        return 2
     group = parallel.WORLD if shard else None
     prefetch = not shard and args.prefetch
 
@@ -320,7 +341,7 @@ def worker(args) -> int:
     ps = PairSet(cfg, B, dev, 0 if shard else 1000 * rank)
     lib = _lib.load()
     for _ in range(args.warmup):
-        step(ps, cfg, group, prefetch, not args.no_pose_tail)
+        step(ps, cfg, group, prefetch, not args.no_pose_tail, ess)
     torch.cuda.synchronize()
     # HIP events around single launches inside the entry points (the scoring kernels of both RANSAC
     # runs and the kNN sweep kernel), recorded on the stream those kernels run on
@@ -330,7 +351,7 @@ def worker(args) -> int:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step(ps, cfg, group, prefetch, not args.no_pose_tail)
+        res = step(ps, cfg, group, prefetch, not args.no_pose_tail, ess)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -347,16 +368,18 @@ def worker(args) -> int:
     # tag 0x1000 = kNN sweep kernel; otherwise kind | iteration-block << 8 of a scoring launch.  The
     # scoring time of one RANSAC run is the sum over its iteration blocks (later blocks return at
     # once for problems that already terminated).
-    tot = {"knn2": 0.0, "score_fund": 0.0, "score_pnp": 0.0}
+    tv = "ess" if ess else "fund"                              # the two-view chain of this run
+    tot = {"knn2": 0.0, "score_" + tv: 0.0, "score_pnp": 0.0}
     for i in range(nrec):
-        name = "knn2" if tags[i] == 0x1000 else ("score_fund" if (tags[i] & 0xFF) == 0 else "score_pnp")
+        name = "knn2" if tags[i] == 0x1000 else ("score_pnp" if (tags[i] & 0xFF) == 2 else "score_" + tv)
         tot[name] += float(ms[i]) * 1e-3
     avg = {k: v / args.steps for k, v in tot.items()}
 
     # ---- what this rank's launches processed, counted outside the timed region from the last step's outputs
-    NQ, NT, HF, HP = cfg["nq"], cfg["nt"], cfg["f_iters"], cfg["p_iters"]
+    NQ, NT, HP = cfg["nq"], cfg["nt"], cfg["p_iters"]
+    HF = E_SAMPLES if ess else cfg["f_iters"]                  # samples of the two-view chain
     n_match = res.n_match.cpu().numpy().astype(np.int64)
-    res_f = res.f_result.cpu().numpy()
+    res_f = (res.e_result if ess else res.f_result).cpu().numpy()
     res_p = res.p_result.cpu().numpy() if res.p_result is not None else np.zeros((B, 4), np.int32)
     # shard mode: this rank scores its slice of every F problem's iterations and whole PnP problems of its pairs
     h_f = parallel.shard_bounds(HF, rank, world) if shard else (0, HF)
@@ -364,16 +387,20 @@ def worker(args) -> int:
     nm_f, nm_p = [], []
     for b in range(B):
         n = int(n_match[b])
-        nm_f.append(ops.solve_7pt(res.f_samples[b, h_f[0]:h_f[1]], res.pts4[b, :n])[1].cpu().numpy())
+        if ess:
+            nm_f.append(ops.solve_5pt(res.e_samples[b], res.pts4n[b, :n])[1].cpu().numpy())
+        else:
+            nm_f.append(ops.solve_7pt(res.f_samples[b, h_f[0]:h_f[1]], res.pts4[b, :n])[1].cpu().numpy())
     for b in (p_pairs if HP > 0 else []):
         n = int(n_match[b])
         nm_p.append(ops.solve_p3p(res.p_samples[b], res.obj[b, :n], res.img[b, :n], ps.K)[2].cpu().numpy())
-    mf = [int(x.sum()) for x in nm_f] if shard else models_scored(nm_f, res_f, HF, 0)
+    mf = [int(x.sum()) for x in nm_f] if shard else models_scored(nm_f, res_f, HF, FIRST_BLOCK if ess else 0)
     mp = models_scored(nm_p, res_p[list(p_pairs)], HP, FIRST_BLOCK) if HP > 0 else []
     evals_f = int(sum(m * n for m, n in zip(mf, n_match)))
     evals_p = int(sum(m * n for m, n in zip(mp, n_match[list(p_pairs)])))
     n_models_f, n_models_p = int(sum(mf)), int(sum(mp))
     nq_local = (parallel.shard_bounds(NQ, rank, world)[1] - parallel.shard_bounds(NQ, rank, world)[0]) if shard else NQ
+    unfinished = int((res_f[:, 3] > HF).sum()) if ess else 0   # E pairs whose adaptive loop wants more samples than were evaluated
 
     prop = torch.cuda.get_device_properties(dev)
     cus = prop.multi_processor_count
@@ -382,62 +409,63 @@ def worker(args) -> int:
     fp64_peak = cus * FP64_FLOP_PER_CLK_CU * CLOCK_GHZ * 1e9 / 1e12
 
     # physical HBM traffic, SQ instruction counts and the clock under load come from rocprofv3 --pmc passes of
-    # this same command (scripts/gpu_roofline.sh -> profiles/r2_counters.json); the per-evaluation instruction
-    # count of the F scoring loop from the disassembled code object (scripts/isa_count.py -> profiles/r2_score_fund_isa.json)
-    ctr = _load_json("r2_counters.json") or {}
-    isa = _load_json("r2_score_fund_isa.json") or {}
-    same_shape = ctr.get("_pairs") == B and ctr.get("_config", "cfg4") == args.config and not shard
+    # this same command (scripts/gpu_roofline.sh -> profiles/r3_counters.json); the per-evaluation instruction counts
+    # of the scoring loops from the disassembled code object (scripts/isa_count.py -> profiles/r3_score_*_isa.json)
+    ctr = _load_json(f"{PROFILE_TAG}_counters.json") or {}
+    same_shape = ctr.get("_pairs") == B and ctr.get("_config", "cfg4") == args.config and not shard and not ess
     kc = lambda k: (ctr.get(k) or {}) if same_shape else {}
-    valu_per_eval = isa.get("valu_per_evaluation")
-    t_f = max(avg["score_fund"], 1e-12)
+    t_f = max(avg["score_" + tv], 1e-12)
     t_p = max(avg["score_pnp"], 1e-12)
     t_k = max(avg["knn2"], 1e-12)
-    sf = {"kernel": "score_kernel<F>", "bound": "valu-issue", "unit": "T VALU lane-instructions/s",
-          "peak": valu_peak, "traffic": kc("score_fund_kernel").get("hbm_bytes_per_launch"),
-          "units_per_launch": f"{evals_f} (model, correspondence) evaluations = {n_models_f} models x the pair's "
-                              f"correspondences ({B} frame pairs)"}
-    if valu_per_eval:
-        sf["achieved"] = evals_f * valu_per_eval / t_f / 1e12
-        sf["frac"] = sf["achieved"] / valu_peak
-        sf["valu_instructions_per_evaluation"] = valu_per_eval
-        sf["all_instructions_per_evaluation"] = isa.get("all_per_evaluation")
-        sf["note"] = (f"achieved = evaluations x {valu_per_eval} VALU instructions per evaluation (tier 1a, the one-sided "
-                      "sure-outlier test every evaluation goes through: inner loop of the shipped code object, "
-                      "profiles/r2_score_fund_isa.json; one lane = one model) / launch time; the ~2.5 % of evaluations that go on to "
-                      "the pooled f32 filter and the ~0.2 % that reach the f64 / exact tier are overhead, not counted "
-                      f"(valu_per_evaluation_from_SQ_INSTS_VALU counts everything executed); peak = {cus} CU x "
-                      f"4 SIMD x 32 lanes/clk x {CLOCK_GHZ} GHz (a wave64 VALU instruction issues over 2 cycles).  The kernel "
-                      "keeps 256 models in registers per workgroup and re-reads correspondences from LDS, so it is bound "
-                      "by instruction issue, not by HBM (traffic = measured HBM bytes per launch)")
-        c = kc("score_fund_kernel")
-        if c.get("clock_ghz"):
-            sf["clock_ghz_under_load"] = c["clock_ghz"]
-            sf["frac_at_measured_clock"] = sf["achieved"] / (cus * VALU_LANES_PER_CLK_CU * c["clock_ghz"] * 1e9 / 1e12)
-        if c.get("SQ_INSTS_VALU") and c.get("evaluations_per_launch"):
-            sf["valu_per_evaluation_from_SQ_INSTS_VALU"] = c["SQ_INSTS_VALU"] * 64 / c["evaluations_per_launch"]
-    else:
-        sf["achieved"], sf["frac"] = None, None
-        sf["note"] = "profiles/r2_score_fund_isa.json missing: run scripts/isa_count.py"
-    sf["effective_streaming_GBps"] = (evals_f * 16 + n_models_f * (72 + 4)) / t_f / 1e9
-    sf["effective_streaming_note"] = ("SURVEY.md 8d's figure: 16 B per evaluation as if every model streamed every correspondence "
-                                      f"from HBM; not a roofline for this kernel ({HBM_PEAK_GBS:.0f} GB/s peak is never touched)")
-    sf["f64_tflops_equivalent"] = evals_f * 49 / t_f / 1e12
-    sf["f64_equivalent_note"] = ("49 f64 flops per evaluation of the scalar definition whose verdicts the kernel reproduces bit "
-                                 "for bit; executed as ~17 f32 instructions + the filter tiers for the few near the threshold")
-    sp_flops = evals_p * 30 / t_p / 1e12
+    tiers = {"fund": "tier 1a, the one-sided sure-outlier test every evaluation goes through; the ~2.5 % of evaluations that go on to "
+                     "the pooled f32 filter and the ~0.2 % that reach the f64 / exact tier are overhead, not counted",
+             "ess": "the two-sided f32 sign-bit Sampson filter every evaluation goes through; the exact f64 evaluation of the few it "
+                    "cannot decide is overhead, not counted",
+             "pnp": "the division-free f32 sign-bit reprojection filter every evaluation goes through; the exact f64 projection of "
+                    "the few it cannot decide is overhead, not counted"}
+
+    def valu_roofline(kind, template_arg, evals, n_models, t, stream_bytes, model_bytes, ckey):
+        isa = _load_json(f"{PROFILE_TAG}_score_{kind}_isa.json") or {}
+        vpe = isa.get("valu_per_evaluation")
+        r = {"kernel": f"score_kernel<{template_arg}>", "bound": "valu-issue", "unit": "T VALU lane-instructions/s", "peak": valu_peak,
+             "traffic": kc(ckey).get("hbm_bytes_per_launch"),
+             "units_per_launch": f"{evals} (model, correspondence) evaluations = {n_models} models x the pair's correspondences ({B} frame pairs)"}
+        if vpe and evals:
+            r["achieved"] = evals * vpe / t / 1e12
+            r["frac"] = r["achieved"] / valu_peak
+            r["valu_instructions_per_evaluation"] = vpe
+            r["all_instructions_per_evaluation"] = isa.get("all_per_evaluation")
+            r["note"] = (f"achieved = evaluations x {vpe} VALU instructions per evaluation ({tiers[kind]}: inner loop of the shipped "
+                         f"code object, profiles/{PROFILE_TAG}_score_{kind}_isa.json; one lane = one model) / launch time; peak = {cus} CU x 4 SIMD x "
+                         f"32 lanes/clk x {CLOCK_GHZ} GHz (a wave64 VALU instruction issues over 2 cycles).  The kernel keeps 256 models in "
+                         "registers per workgroup and re-reads correspondences from LDS, so it is bound by instruction issue, not by HBM "
+                         "(traffic = measured HBM bytes per launch)")
+            c = kc(ckey)
+            if c.get("clock_ghz"):
+                r["clock_ghz_under_load"] = c["clock_ghz"]
+                r["frac_at_measured_clock"] = r["achieved"] / (cus * VALU_LANES_PER_CLK_CU * c["clock_ghz"] * 1e9 / 1e12)
+            if c.get("SQ_INSTS_VALU") and c.get("evaluations_per_launch"):
+                r["valu_per_evaluation_from_SQ_INSTS_VALU"] = c["SQ_INSTS_VALU"] * 64 / c["evaluations_per_launch"]
+        else:
+            r["achieved"], r["frac"] = None, None
+            r["note"] = f"profiles/{PROFILE_TAG}_score_{kind}_isa.json missing (run scripts/isa_count.py) or nothing was scored"
+        r["effective_streaming_GBps"] = (evals * stream_bytes + n_models * (model_bytes + 4)) / t / 1e9
+        r["effective_streaming_note"] = (f"SURVEY.md 8d's figure: {stream_bytes} B per evaluation as if every model streamed every "
+                                         f"correspondence from HBM; not a roofline for this kernel ({HBM_PEAK_GBS:.0f} GB/s peak is never touched)")
+        return r
+
+    sf = valu_roofline(tv, "E" if ess else "F", evals_f, n_models_f, t_f, 32 if ess else 16, 72, f"score_{tv}_kernel")
+    sp = valu_roofline("pnp", "PnP", evals_p, n_models_p, t_p, 20, 96, "score_pnp_kernel")
+    sp["note"] = (sp.get("note") or "") + ("; in weak mode the PnP chain runs on a side stream under the two-view chain, so these launches "
+                                           "share the GPU and their durations are upper bounds (standalone: profiles/r3_score_standalone.json)")
+    sp["units_per_launch"] += f", {len(iteration_blocks(HP, FIRST_BLOCK))} iteration-block launches summed"
     roof = {
-        "score_fund": sf,
-        "score_pnp": {"kernel": "score_kernel<PnP>", "bound": "fp64-valu", "achieved": sp_flops, "peak": fp64_peak,
-                      "unit": "TFLOP/s", "frac": sp_flops / fp64_peak, "traffic": None,
-                      "effective_streaming_GBps": (evals_p * 20 + n_models_p * (96 + 4)) / t_p / 1e9,
-                      "note": "30 f64 flops per evaluation (SURVEY.md 8d: 3x4 projection, one correctly rounded divide, pixel "
-                              "mapping); in weak mode the PnP chain runs on a side stream under the F chain, so these launches "
-                              "share the GPU and their durations are upper bounds; standalone figures: profiles/r2_score_standalone.json",
-                      "units_per_launch": f"{evals_p} evaluations = {n_models_p} models x the pair's correspondences "
-                                          f"({B} frame pairs, {len(iteration_blocks(HP, FIRST_BLOCK))} iteration-block launches summed)"},
+        "score_" + tv: sf,
+        "score_pnp": sp,
         "knn2": {"kernel": "knn2_partial_kernel", "bound": "mfma", "achieved": 2.0 * nq_local * NT * 128 * B / t_k / 1e12,
                  "peak": i8_peak_tops, "unit": "TOP/s", "traffic": kc("knn2_partial_kernel").get("hbm_bytes_per_launch"),
-                 "note": f"int8 dense peak = {cus} CU x {I8_OPS_PER_CLK_CU} ops/clk x {CLOCK_GHZ} GHz; see DESIGN.md 4.1",
+                 "note": f"int8 dense peak = {cus} CU x {I8_OPS_PER_CLK_CU} ops/clk x {CLOCK_GHZ} GHz; under this kernel the chip holds "
+                         "1.8-1.9 GHz (power), see clock_ghz_under_load and DESIGN.md 4.1",
                  "units_per_launch": f"{B} frame pairs of {nq_local} x {NT} descriptors"},
     }
     roof["knn2"]["frac"] = roof["knn2"]["achieved"] / i8_peak_tops
@@ -455,9 +483,16 @@ def worker(args) -> int:
                   f"P3P PnP-RANSAC with maxIters {HP} over them with 55 % of the landmarks replaced by unrelated points "
                   f"(OpenCV's adaptive loop runs a few hundred iterations; blocks of 64, 320, 1600, ... are scored) + EPnP refit, "
                   f"and the {HF}-iteration 7-point F-RANSAC, per frame pair"}[args.config]
-    wl += ("; both chains end at a pose: the 2D-2D chain goes on through E = K^T F K, decomposeEssentialMatrix and "
-           "disambiguateRelativePose over the F inliers (device pose tail, R,t + triangulated points out), the 3D-2D chain ends "
-           "with the EPnP refit" if not args.no_pose_tail else "; the 2D-2D chain stops at F (--no-pose-tail)")
+    if ess:
+        wl = (f"{args.config} with the essential-matrix form of the 2D-2D chain (reference src/utils/geometry.py:43-45): {NQ}x{NT}x128 SIFT "
+              f"match + ratio test -> matched correspondences -> five-point E-RANSAC (cv2.findEssentialMat defaults of the reference: "
+              f"threshold {E_THR} px, confidence {E_CONF}, maxIters {E_MAX_ITERS}; Sampson distance on K-normalised f64 coordinates; "
+              f"{E_SAMPLES} getSubset samples per pair in blocks of {FIRST_BLOCK}, x5, ...: OpenCV's adaptive loop ends after a few dozen) "
+              f"and P3P PnP-RANSAC with maxIters {HP} (+ EPnP refit), per frame pair; the chain ends at (E, mask) as the reference's wrapper does")
+    else:
+        wl += ("; both chains end at a pose: the 2D-2D chain goes on through E = K^T F K, decomposeEssentialMatrix and "
+               "disambiguateRelativePose over the F inliers (device pose tail on a side stream, R,t + triangulated points out), the "
+               "3D-2D chain ends with the EPnP refit" if not args.no_pose_tail else "; the 2D-2D chain stops at F (--no-pose-tail)")
     par_note = (f"ONE batch of {B} pairs over {world} GPU(s): query rows split for the match (all_gather of the 2-NN rows), "
                 "F-RANSAC iteration ranges split over the ranks (all_gather of count tables + all-reduce of winners, replicated replay), "
                 "PnP problems dealt to the ranks by pair (all_gather of the packed results)"
@@ -466,21 +501,23 @@ def worker(args) -> int:
         "metric": "matched frame-pairs/sec", "value": pairs_total / dt, "unit": "frame-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
-        "dtype": "i8 (matching) / f64 (RANSAC; F scoring filtered in f32, verdicts identical)",
+        "dtype": "i8 (matching) / f64 (RANSAC; scoring filtered in f32, verdicts identical)",
         "data": "synthetic",
         "data_note": "every frame pair of a step is a different synthetic scene (4 from the host generator -- the ones the CPU "
                      "baseline runs -- the rest from the device generator of the same recipe); random-init, no dataset",
         "config": {"workload": wl, "pairs_per_step": B if shard else B * world, "pairs_per_gpu_per_step": None if shard else B,
-                   "mode": args.mode, "pose_tail_in_step": not args.no_pose_tail, "descriptor_prefetch": prefetch, "parallelism": par_note, "process_group": f"nccl (RCCL), world size {world}"},
+                   "mode": args.mode, "two_view_chain": "essential (5-point, Sampson)" if ess else "fundamental (7-point, symmetric epipolar)",
+                   "pose_tail_in_step": not args.no_pose_tail and not ess, "descriptor_prefetch": prefetch, "parallelism": par_note, "process_group": f"nccl (RCCL), world size {world}"},
         "ransac_scoring": {"metric": "RANSAC hypotheses x points scored/sec",
                            "value": evals_f / t_f,
-                           "unit": "evaluations/s per GPU inside the F scoring kernel (models that exist x correspondences)",
+                           "unit": f"evaluations/s per GPU inside the {'E' if ess else 'F'} scoring kernel (models that exist x correspondences)",
+                           "two_view_pairs_needing_more_samples": unfinished,
                            "pnp_value": evals_p / t_p,
                            "whole_job_evals_per_s": (evals_f + evals_p) * world * args.steps / dt,
                            "matches_per_pair": float(n_match.mean()),
-                           "models_scored_per_pair": {"fund": n_models_f / B, "pnp": n_models_p / B},
-                           "inliers_per_pair": {"fund": float(res_f[:, 2].mean()), "pnp": float(res_p[:, 2].mean())},
-                           "final_niters_first_pairs": {"fund": [int(v) for v in res_f[:4, 3]], "pnp": [int(v) for v in res_p[:4, 3]]}},
+                           "models_scored_per_pair": {tv: n_models_f / B, "pnp": n_models_p / B},
+                           "inliers_per_pair": {tv: float(res_f[:, 2].mean()), "pnp": float(res_p[:, 2].mean())},
+                           "final_niters_first_pairs": {tv: [int(v) for v in res_f[:4, 3]], "pnp": [int(v) for v in res_p[:4, 3]]}},
         "kernel_time_share": {k: v / dt for k, v in tot.items()},
         "kernel_avg_us": {k: v * 1e6 for k, v in avg.items()},
         "roofline": roof[dominant],
@@ -488,9 +525,9 @@ def worker(args) -> int:
         "device": prop.name, "cus": cus,
     }
     if rank == 0:
-        solo = world == 1 and args.config == "cfg4"
+        solo = world == 1 and args.config == "cfg4" and not ess
         line["drop_in_latency"] = drop_in_latency(cfg) if (solo and not args.no_latency) else None
-        line["cpu_baseline"] = cpu_baseline(cfg) if (world == 1 and not args.no_cpu) else None
+        line["cpu_baseline"] = cpu_baseline(cfg, ess=ess) if (world == 1 and not args.no_cpu) else None
         print(json.dumps(line), flush=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -509,6 +546,9 @@ def main() -> int:
     ap.add_argument("--prefetch", action="store_true",
                     help="weak mode: convert the next step's descriptors underneath this step's scoring (pipeline.prepare_descriptors; "
                          "measured neutral: 9.17 vs 9.16 ms per step, DESIGN.md section 7)")
+    ap.add_argument("--ransac", choices=["fund", "ess"], default="fund",
+                    help="the two-view chain: 7-point F-RANSAC (the reference's live path, default) or five-point E-RANSAC with the "
+                         "reference's calc_essential_mat defaults (its dormant path)")
     ap.add_argument("--no-pose-tail", action="store_true",
                     help="end the 2D-2D chain at F (round-2 workload) instead of at the relative pose (A/B of the pose tail's cost)")
     ap.add_argument("--no-pnp", action="store_true", help="A/B only: drop the PnP chain (side stream) from the step")

@@ -107,6 +107,31 @@ def test_pair_pipeline_matches_oracle_chain(det_math, dev):
         assert np.array_equal(np.nonzero(pm[:n[b]])[0], inl.ravel()) and not pm[n[b]:].any()
 
 
+def test_pair_pipeline_essential_chain_matches_oracle(det_math, dev):
+    """The essential-matrix chain inside the batch (match -> K-normalisation -> five-point E-RANSAC in iteration blocks)
+    equals cv2.findEssentialMat's restatement on the same matches with the reference's maxIters of 50000: E, mask and
+    the (iteration, model, inliers, niters) record, bit for bit; the F chain can be left out (f_iters = 0) or run beside it."""
+    o = det_math
+    B, nq, nt, He = 3, 1200, 1300, 512
+    pairs = [_pair(500 + b, nq, nt) for b in range(B)]
+    st = lambda k: _d(np.stack([p[k] for p in pairs]), dev)
+    K = synth.K_MALAGA
+    for f_iters, first in ((0, 64), (100, 0)):
+        r = pipeline.match_and_ransac(st(0), st(1), st(2), st(3), 0.8, 1.0, 0.999, f_iters, K=K, e_iters=He, e_threshold=1.0,
+                                      e_confidence=0.9999, e_max_iters=50000, first_block_e=first)
+        assert (r.F is None) == (f_iters == 0)
+        n = r.n_match.cpu().numpy()
+        for b, (q, t, kq, kt, xyz) in enumerate(pairs):
+            oq, ot, _, _ = o.match_features_indices(q, t, 0.8)
+            p1, p2 = kq[oq].astype(np.float64), kt[ot].astype(np.float64)
+            E, mask, info = o.find_essential_mat(p1, p2, K, 0.9999, 1.0, 50000)
+            assert int(info[3]) <= He                         # OpenCV's loop ended within the samples evaluated
+            assert tuple(r.e_result[b].cpu().numpy()) == tuple(int(v) for v in info)
+            assert np.array_equal(r.E[b].cpu().numpy().reshape(3, 3), E)
+            em = r.e_mask[b].cpu().numpy()
+            assert np.array_equal(em[:n[b]], mask.ravel()) and not em[n[b]:].any() and mask.sum() > 50
+
+
 def test_sweep_device_generated_pairs_vs_oracle(det_math, dev):
     """sweep.run_sweep: pairs generated on the device, table rows checked against the oracle chain on
     the same (downloaded) data; the recovered pose is the scene's."""

@@ -44,6 +44,11 @@ class PairBatchResult:
     img: Optional[torch.Tensor] = None
     f7_models: Optional[torch.Tensor] = None     # (B,3,9) f64 every 7-point solution of the pairs with EXACTLY 7 matches (cv2 stacks them)
     f7_count: Optional[torch.Tensor] = None      # (B,) i32 how many (0 for every other pair)
+    e_result: Optional[torch.Tensor] = None      # (B,4) i32  the essential-matrix chain (e_iters > 0): as f_result
+    E: Optional[torch.Tensor] = None             # (B,9) f64  best five-point model
+    e_mask: Optional[torch.Tensor] = None        # (B,nq) u8  its Sampson inliers over the matched correspondences
+    e_samples: Optional[torch.Tensor] = None     # (B,e_iters,5) i32
+    pts4n: Optional[torch.Tensor] = None         # (B,nq,4) f64 the K-normalised correspondences the E chain ran on
     desc_flags: Optional[torch.Tensor] = None    # (2,) i32 VO_DESC_BAD_* bits of the query / train descriptors: callers
                                                  # MUST check it (check_descriptors) where they synchronise anyway --
                                                  # the int8 matcher is only exact for integer 0..255 rows of norm <= 1024
@@ -174,7 +179,8 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
                      xyz_q: Optional[torch.Tensor] = None, K=None, p_threshold: float = 1.0, p_confidence: float = 0.9999,
                      p_iters: int = 0, first_block_f: int = 0, first_block_pnp: int = 0,
                      workspace: Optional[torch.Tensor] = None, wait_pnp: bool = True, group=None,
-                     prepared: Optional[PreparedDescriptors] = None) -> PairBatchResult:
+                     prepared: Optional[PreparedDescriptors] = None, e_iters: int = 0, e_threshold: float = 1.0,
+                     e_confidence: float = 0.9999, e_max_iters: Optional[int] = None, first_block_e: int = 0) -> PairBatchResult:
     """desc_* (B,n,128) f32 integer-valued, kp_* (B,n,2) f32, xyz_q (B,nq,3) f32 landmarks of the query
     keypoints (enables the PnP run when p_iters > 0).  first_block_*: see ops.ransac_batch (0 = evaluate all
     iterations at once).  Everything is enqueued on the current stream, except the PnP chain (P3P RANSAC +
@@ -190,9 +196,18 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
     prepared: the descriptors' int8 conversion done ahead of time on the prefetch stream (prepare_descriptors); the
     conversion is then not repeated here.
 
+    e_iters > 0 (needs K): the essential-matrix chain of src/utils/geometry.py:43-45 as well -- cv2.findEssentialMat(p1, p2,
+    K, RANSAC, e_confidence, e_threshold, e_max_iters) over the matches: five-point models of `e_iters` getSubset samples
+    scored by the Sampson distance on K-normalised f64 coordinates, threshold / ((fx + fy) / 2).  e_max_iters is OpenCV's
+    maxIters (the reference's default is 50000) and defaults to e_iters; the answer is OpenCV's as long as its adaptive
+    loop ends within the e_iters samples evaluated (e_result[:, 3] <= e_iters -- check it where you synchronise anyway).
+    f_iters = 0 skips the fundamental-matrix chain.
+
     group (parallel.WORLD or a process group): ONE batch over several GPUs -- every rank passes the same
     inputs and gets the same outputs; see match_and_ransac_sharded."""
     if group is not None:
+        if e_iters > 0 or f_iters <= 0:
+            raise ops._lib.VoError("match_and_ransac: the essential-matrix chain is not available together with `group`")
         if prepared is not None or first_block_f != 0:
             raise ops._lib.VoError("match_and_ransac: `prepared` and `first_block_f` are not supported together with `group` "
                                    "(the sharded path converts its own query slice and evaluates every F iteration); "
@@ -239,14 +254,34 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
             pnp_out = (p_res, pose, rvec, p_mask, p_samples, refined, p_ok)
             for t in pnp_out + (n_p,):
                 t.record_stream(main)              # allocated on the side stream, consumed on the caller's
-    # fewer than 15 matches: OpenCV would not run 7-point RANSAC; feed an empty problem instead
-    n_f = torch.where(n >= 15, n, torch.zeros_like(n))
-    f_samples, _ = ops.gen_subsets_device(n_f, nq, 7, f_iters, c["pts4"])
-    f_res, F, _, f_mask = ops.ransac_batch(ops.KIND_FUND, f_samples, c["pts4"], f_threshold, f_confidence, f_iters,
-                                           n_dev=n_f, workspace=ws_f, first_block=first_block_f)
-    f7, n7 = _small_pairs(c["pts4"], n, f_confidence, f_iters, f_res, F, f_mask, ws_f)
+    f_res = F = f_mask = f_samples = f7 = n7 = None
+    if f_iters > 0:
+        # fewer than 15 matches: OpenCV would not run 7-point RANSAC; feed an empty problem instead
+        n_f = torch.where(n >= 15, n, torch.zeros_like(n))
+        f_samples, _ = ops.gen_subsets_device(n_f, nq, 7, f_iters, c["pts4"])
+        f_res, F, _, f_mask = ops.ransac_batch(ops.KIND_FUND, f_samples, c["pts4"], f_threshold, f_confidence, f_iters,
+                                               n_dev=n_f, workspace=ws_f, first_block=first_block_f)
+        f7, n7 = _small_pairs(c["pts4"], n, f_confidence, f_iters, f_res, F, f_mask, ws_f)
     out = PairBatchResult(idx, d2, c["match_q"], c["match_t"], n, c["pts4"], f_res, F, f_mask, f_samples=f_samples,
                           desc_flags=flags, f7_models=f7, f7_count=n7)
+    if e_iters > 0:
+        if K is None:
+            raise ops._lib.VoError("match_and_ransac: the essential-matrix chain needs K")
+        import numpy as _np
+        Kh = _np.asarray(K, dtype=_np.float64)
+        fx, fy, cx, cy = float(Kh[0, 0]), float(Kh[1, 1]), float(Kh[0, 2]), float(Kh[1, 2])
+        ifx, ify = 1.0 / fx, 1.0 / fy
+        # cv2.findEssentialMat's normalisation, the operations of ransac.find_essential_ransac: u * (1/fx) + (-cx * (1/fx))
+        scale = torch.tensor([ifx, ify, ifx, ify], dtype=torch.float64, device=desc_q.device)
+        shift = torch.tensor([-cx * ifx, -cy * ify, -cx * ifx, -cy * ify], dtype=torch.float64, device=desc_q.device)
+        pts4n = c["pts4"].to(torch.float64) * scale
+        pts4n = pts4n + shift
+        # 6+ matches run the RANSAC registrator (exactly 5 would return every solution stacked: single-pair entry point only)
+        n_e = torch.where(n >= 6, n, torch.zeros_like(n))
+        e_samples, _ = ops.gen_subsets_device(n_e, nq, 5, e_iters, None)
+        e_res, E, _, e_mask = ops.ransac_batch(ops.KIND_ESS, e_samples, pts4n, e_threshold / ((fx + fy) / 2), e_confidence,
+                                               e_max_iters if e_max_iters else e_iters, n_dev=n_e, first_block=first_block_e)
+        out.e_result, out.E, out.e_mask, out.e_samples, out.pts4n = e_res, E, e_mask, e_samples, pts4n
     if do_pnp:
         out.pnp_done = side.record_event()
         if wait_pnp:
