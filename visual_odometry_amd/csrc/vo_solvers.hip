@@ -530,6 +530,134 @@ __device__ int solve_deg4(double a, double b, double c, double d, double e, doub
     return nb;
 }
 
+// jacobi_svd<true>(At, 3, 3, 3, W, Vt) in registers: every index a compile-time constant, same pair order and operation
+// order, so the bits agree.  On exit rows of At = left singular vectors (if COMPLETE: normalised, degenerate ones replaced
+// exactly as the generic routine does), W descending, Vt = V^T.  A lane that has converged rides along with the sweeps
+// other lanes still need: with nothing left to rotate it changes nothing.
+template <bool COMPLETE>
+__device__ __forceinline__ void jacobi3_svd(double (&At)[3][3], double (&W)[3], double (&Vt)[3][3])
+{
+    const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sd += At[i][k] * At[i][k];
+        W[i] = sd;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Vt[i][k] = i == k ? 1. : 0.;
+    }
+#pragma unroll 1
+    for (int iter = 0; iter < 30; ++iter) {
+        bool changed = false;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = i + 1; j < 3; ++j) {
+                double a = W[i], p = 0, b = W[j];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) p += At[i][k] * At[j][k];
+                if (!(fabs(p) <= eps * sqrt(a * b))) {
+                    p *= 2;
+                    const double beta = a - b, gamma = sqrt(p * p + beta * beta);
+                    double c, s;
+                    if (beta < 0) {
+                        const double delta = (gamma - beta) * 0.5;
+                        s = sqrt(delta / gamma);
+                        c = p / (gamma * s * 2);
+                    } else {
+                        c = sqrt((gamma + beta) / (gamma * 2));
+                        s = p / (gamma * c * 2);
+                    }
+                    a = b = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const double t0 = c * At[i][k] + s * At[j][k];
+                        const double t1 = -s * At[i][k] + c * At[j][k];
+                        At[i][k] = t0; At[j][k] = t1;
+                        a += t0 * t0; b += t1 * t1;
+                    }
+                    W[i] = a; W[j] = b;
+                    changed = true;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const double t0 = c * Vt[i][k] + s * Vt[j][k];
+                        const double t1 = -s * Vt[i][k] + c * Vt[j][k];
+                        Vt[i][k] = t0; Vt[j][k] = t1;
+                    }
+                }
+            }
+        if (!__any(changed)) break;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sd += At[i][k] * At[i][k];
+        W[i] = sqrt(sd);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int j = i;
+        double wj = W[i];
+#pragma unroll
+        for (int k = i + 1; k < 3; ++k)
+            if (wj < W[k]) { j = k; wj = W[k]; }
+#pragma unroll
+        for (int k = i + 1; k < 3; ++k)
+            if (j == k) {
+                double t = W[i]; W[i] = W[k]; W[k] = t;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    t = At[i][e]; At[i][e] = At[k][e]; At[k][e] = t;
+                    t = Vt[i][e]; Vt[i][e] = Vt[k][e]; Vt[k][e] = t;
+                }
+            }
+    }
+    if (!COMPLETE) return;
+    unsigned long long rs = 0x12345678ULL;              // per lane: only degenerate rows draw from it
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double sd = W[i];
+#pragma unroll 1
+        for (int ii = 0; ii < 100 && __any(sd <= minval); ++ii) {
+            if (sd <= minval) {
+                const double val0 = 1. / 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    rs = (unsigned long long)(unsigned)rs * 4164903690u + (unsigned)(rs >> 32);
+                    At[i][k] = ((unsigned)rs & 256) != 0 ? val0 : -val0;
+                }
+#pragma unroll 1
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int j = 0; j < i; ++j) {
+                        double d = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) d += At[i][k] * At[j][k];
+                        double asum = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const double t = At[i][k] - d * At[j][k];
+                            At[i][k] = t;
+                            asum += fabs(t);
+                        }
+                        asum = asum > eps * 100 ? 1 / asum : 0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) At[i][k] *= asum;
+                    }
+                double q = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) q += At[i][k] * At[i][k];
+                sd = sqrt(q);
+            }
+        }
+        const double sc = sd > minval ? 1 / sd : 0.;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) At[i][k] *= sc;
+    }
+}
+
 // ------------------------------------------------------------------------------ Rodrigues
 __device__ void rodrigues_v2m(const double* r_in, double* R)
 {
@@ -551,26 +679,27 @@ __device__ void rodrigues_v2m(const double* r_in, double* R)
     for (int k = 0; k < 9; ++k) R[k] = (c * I[k] + c1 * rrt[k]) + s * r_x[k];
 }
 
-// scratch: 21 doubles per lane in LDS (At 9, W 3, Vt 9)
-__device__ void rodrigues_m2v(const double* Rin, double* rvec, SV scratch)
+__device__ void rodrigues_m2v(const double* Rin, double* rvec)
 {
-    const SV At = scratch, W = scratch.at(9), Vt = scratch.at(12);
+    double At[3][3], W[3], Vt[3][3];
     bool in_range = true;
 #pragma unroll
     for (int k = 0; k < 9; ++k) in_range &= (Rin[k] > -100 && Rin[k] < 100);
-    if (!in_range) { rvec[0] = rvec[1] = rvec[2] = 0; return; }
+    // lanes whose matrix is out of range ride through the (wave-uniform) SVD loops on a harmless identity
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) At[i * 3 + j] = Rin[j * 3 + i];
-    jacobi_svd<true>(At, 3, 3, 3, W, Vt);
+        for (int j = 0; j < 3; ++j) At[i][j] = in_range ? Rin[j * 3 + i] : (i == j ? 1. : 0.);
+    jacobi3_svd<true>(At, W, Vt);
+    if (!in_range) { rvec[0] = rvec[1] = rvec[2] = 0; return; }
     double R[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             double s = 0;
-            for (int k = 0; k < 3; ++k) s += At[k * 3 + i] * Vt[k * 3 + j];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s += At[k][i] * Vt[k][j];
             R[i * 3 + j] = s;
         }
     double x = R[7] - R[5], y = R[2] - R[6], z = R[3] - R[1];
@@ -787,7 +916,6 @@ void solve_p3p_kernel(const int32_t* __restrict__ samples, int H, const float* _
                       int per, int32_t* __restrict__ list, int32_t* __restrict__ nlist, const int32_t* __restrict__ n_dev,
                       int h0, int hlen, const int32_t* __restrict__ prev)
 {
-    __shared__ double lds[21 * kLanes];
     // thread -> (problem b, iteration h0 + i) for the iteration block [h0, h0 + hlen) of every problem;
     // a problem whose sequential loop already ended (prev = its replay result, niters <= h0) is skipped
     const int tix = blockIdx.x * kLanes + threadIdx.x;
@@ -800,7 +928,6 @@ void solve_p3p_kernel(const int32_t* __restrict__ samples, int H, const float* _
     const int nb_pts = n_dev ? min(n_dev[b], N) : N;
     obj += (size_t)b * N * 3;
     img += (size_t)b * N;
-    const SV scratch{lds + threadIdx.x};
 
     const double ifx = 1. / fx, ify = 1. / fy;
     const double inv_fx = 1. / fx, inv_fy = 1. / fy, cx_fx = cx / fx, cy_fy = cy / fy;
@@ -876,7 +1003,7 @@ void solve_p3p_kernel(const int32_t* __restrict__ samples, int H, const float* _
     for (int s = 0; s < nb; ++s) {
         const int o = order[s];
         double Rr[9];
-        rodrigues_m2v(Rs[o], rvs[o], scratch);
+        rodrigues_m2v(Rs[o], rvs[o]);
         rodrigues_v2m(rvs[o], Rr);
         double e = 0;
 #pragma unroll
@@ -1048,86 +1175,12 @@ __device__ __forceinline__ void solve_poly_fixed(const double (&c)[N + 1], doubl
         if (fabs(im[i]) < 1e-100) im[i] = 0;
 }
 
-// Right singular vector of the smallest singular value of a 3 x 3 matrix: jacobi_svd<true>(At, 3, 3, 3) in registers
-// (rows of At = columns of the matrix), same pair order and operation order; returns the last row of V^T after the
-// descending sort.  The completion of degenerate left singular vectors is skipped: it never touches V.
+// Right singular vector of the smallest singular value of a 3 x 3 matrix (rows of At = columns of the matrix): the last
+// row of V^T after the descending sort.  The completion of degenerate left singular vectors is skipped: it never touches V.
 __device__ __forceinline__ void jacobi3_last_vt(double (&At)[3][3], double (&out)[3])
 {
-    const double eps = DBL_EPSILON * 10;
     double W[3], Vt[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        double sd = 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) sd += At[i][k] * At[i][k];
-        W[i] = sd;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) Vt[i][k] = i == k ? 1. : 0.;
-    }
-#pragma unroll 1
-    for (int iter = 0; iter < 30; ++iter) {
-        bool changed = false;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = i + 1; j < 3; ++j) {
-                double a = W[i], p = 0, b = W[j];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) p += At[i][k] * At[j][k];
-                if (!(fabs(p) <= eps * sqrt(a * b))) {
-                    p *= 2;
-                    const double beta = a - b, gamma = sqrt(p * p + beta * beta);
-                    double c, s;
-                    if (beta < 0) {
-                        const double delta = (gamma - beta) * 0.5;
-                        s = sqrt(delta / gamma);
-                        c = p / (gamma * s * 2);
-                    } else {
-                        c = sqrt((gamma + beta) / (gamma * 2));
-                        s = p / (gamma * c * 2);
-                    }
-                    a = b = 0;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const double t0 = c * At[i][k] + s * At[j][k];
-                        const double t1 = -s * At[i][k] + c * At[j][k];
-                        At[i][k] = t0; At[j][k] = t1;
-                        a += t0 * t0; b += t1 * t1;
-                    }
-                    W[i] = a; W[j] = b;
-                    changed = true;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const double t0 = c * Vt[i][k] + s * Vt[j][k];
-                        const double t1 = -s * Vt[i][k] + c * Vt[j][k];
-                        Vt[i][k] = t0; Vt[j][k] = t1;
-                    }
-                }
-            }
-        if (!__any(changed)) break;
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        double sd = 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) sd += At[i][k] * At[i][k];
-        W[i] = sqrt(sd);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int j = i;
-        double wj = W[i];
-#pragma unroll
-        for (int k = i + 1; k < 3; ++k)
-            if (wj < W[k]) { j = k; wj = W[k]; }
-#pragma unroll
-        for (int k = i + 1; k < 3; ++k)
-            if (j == k) {
-                double t = W[i]; W[i] = W[k]; W[k] = t;
-#pragma unroll
-                for (int e = 0; e < 3; ++e) { t = Vt[i][e]; Vt[i][e] = Vt[k][e]; Vt[k][e] = t; }
-            }
-    }
+    jacobi3_svd<false>(At, W, Vt);
 #pragma unroll
     for (int k = 0; k < 3; ++k) out[k] = Vt[2][k];
 }
