@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """gpurun_out/<tag>_counters.json from the rocprofv3 outputs of scripts/gpu_roofline.sh: per kernel the average
 duration (kernel trace), SQ counters + clock under load (GRBM_GUI_ACTIVE / 8 / duration of the same dispatch),
-HBM bytes per launch (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md).  Copy to profiles/r2_counters.json."""
+HBM bytes per launch (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md).  Copy to profiles/<tag>_counters.json."""
 import collections
 import csv
 import glob
@@ -74,6 +74,7 @@ except Exception as e:                                    # noqa: BLE001
 res = dict(out)
 res["_pairs"] = pairs
 res["_config"] = "cfg5" if "cfg5" in bench_args else "cfg4"
+res["_ransac"] = "ess" if "ess" in bench_args else "fund"
 res["_how"] = ("scripts/gpu_roofline.sh: `python3 bench.py --inproc --no-cpu --no-latency " + bench_args + "` under rocprofv3 "
                "--kernel-trace --stats (20 steps; trace_avg_us) and three separate --pmc passes of 2 steps each: SQ_* + GRBM_GUI_ACTIVE, "
                "FETCH_SIZE, WRITE_SIZE, averaged over the kernel's dispatches.  clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / dispatch "
