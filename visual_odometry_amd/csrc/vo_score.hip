@@ -242,7 +242,7 @@ __device__ __forceinline__ void fund_filter32_signs(const FundFilter32& f, float
     out_bits = __builtin_amdgcn_alignbit(out_bits, __float_as_uint(r_out), 31);
 }
 
-#ifdef VO_SCORE_STATS
+#if defined(VO_SCORE_STATS) || defined(VO_SCORE_MF_PROF)
 __device__ unsigned long long g_stats[8];
 extern "C" int vo_score_stats(unsigned long long* out8, int reset)
 {
@@ -897,6 +897,14 @@ void score_kernel(const ScoreArgs a)
     if (live && cnt) atomicAdd(a.counts + gslot, cnt);
 }
 
+#ifndef VO_SCORE_F_MFMA
+#define VO_SCORE_F_MFMA 1             // 1: the F count kernel runs its first tier on the matrix cores (vo_score_fmfma.h)
+#endif
+#ifndef VO_SCORE_MF_TARGET
+#define VO_SCORE_MF_TARGET 1024       // workgroups wanted before a workgroup of the MFMA kernel walks more than one chunk
+#endif
+#include "vo_score_fmfma.h"
+
 // ---- mask kernels (one model, thread per correspondence) ----------------------------------
 
 __global__ void mask_fund_kernel(const double* __restrict__ model, const float4* __restrict__ pts, int N,
@@ -1189,6 +1197,21 @@ int vo_launch_score(int kind, const double* models, const uint8_t* valid, const 
     a.models = models; a.valid = valid; a.list = list; a.nstart = nstart; a.nlist = nlist; a.pts = pts; a.img = (const float2*)img;
     a.n_dev = n_dev; a.counts = counts; a.H = H; a.N = N; a.thr2 = thr2;
     if (max_slots <= 0 || max_slots > H) max_slots = H;
+    if (kind == kFund && VO_SCORE_F_MFMA) {
+        // chunks of 512 correspondences; a workgroup walks every gy-th chunk with its models' operands in registers
+        const int nchunks = vo_ceil_div(N, kMfChunk);
+        const long mblocks = (long)vo_ceil_div(max_slots, kThreads) * batch;
+        long gy = (VO_SCORE_MF_TARGET + mblocks - 1) / mblocks;
+        if (gy > nchunks) gy = nchunks;
+        if (gy < 1) gy = 1;
+        VO_CHECK_ARG(batch <= 65535, VO_ESIZE, "score: batch=%d too large", batch);
+        a.chunk = kMfChunk;
+        a.fx = a.fy = a.cx = a.cy = 0;
+        const dim3 grid(vo_ceil_div(max_slots, kThreads), (unsigned)gy, batch);
+        hipLaunchKernelGGL(score_fund_mfma_kernel, grid, dim3(kThreads), 0, s, a, (int)gy);
+        VO_LAUNCH_CHECK();
+        return VO_OK;
+    }
     a.chunk = pick_chunk(max_slots, N, batch);
     a.fx = K4 ? K4[0] : 0; a.fy = K4 ? K4[1] : 0; a.cx = K4 ? K4[2] : 0; a.cy = K4 ? K4[3] : 0;
     VO_CHECK_ARG(vo_ceil_div(N, a.chunk) <= 65535 && batch <= 65535, VO_ESIZE, "score: N=%d or batch=%d too large", N, batch);

@@ -1,0 +1,575 @@
+// vo_score_fmfma.h -- the F count kernel with its first tier on the matrix cores.  Included by vo_score.hip INSIDE its
+// anonymous namespace, after the scalar filters (it reuses fund_filter32, fund_decide64, ScoreArgs, lds_load).
+//
+// What moves to MFMA.  The one-sided sure-outlier test of score_kernel<kFund> (fund_filter32_outlier_sign) needs, per
+// (model, correspondence), d = x2^T F x1 and den2 = a^2 + b^2 with (a b .) = F x1.  Both are inner products of a
+// per-MODEL coefficient vector with a per-POINT feature vector:
+//   d    = sum_k c_k phi_k,   phi = (x2 x1, x2 y1, x2, y2 x1, y2 y1, y2, x1, y1, 1),  c = F row-major
+//   den2 = sum_k G_k psi_k,   psi = (x1^2, x1 y1, y1^2, x1, y1, 1),  G = the quadratic form of rows 0,1 of F
+// so a 32 x 32 tile of evaluations is a small GEMM.  f32 MFMA runs at the VALU's rate and would gain nothing; f16 MFMA
+// is 16x faster but f16 has 11 bits, so every factor is split into hi + lo halves (v ~ hi + lo, |v - hi - lo| <=
+// 2^-22 |v|) and the products hi*hi + hi*lo + lo*hi are laid along K (the MFMA multiplies f16 pairs exactly and sums in
+// f32).  d takes 8 x 3 = 24 K entries (two K=16 steps; the constant term c_8 enters as the accumulator's initial value,
+// in f32), den2 takes 5 x 3 + 1 = 16 (one step): three v_mfma_f32_32x32x16_f16 per 1024 evaluations, 0.094 cycles per
+// evaluation per SIMD against 0.44 for the 14 VALU instructions of the scalar form at its issue peak.  The VALU keeps
+// three instructions per evaluation (r = s + 2 eta |d| - d^2 as two FMAs, the sign bit shifted into a bit string).
+//
+// Error budget of d (unit u = 2^-24 S~, S~ = sum_k |c~_k| B_k + |c~_8| with B_k the chunk-wide bound of |phi~_k|):
+// f32 rounding of the product features 1; the splits of features and coefficients and the dropped lo*lo product, 2^-22
+// relative each: 12; f16 subnormal quantum of the lo halves (2^-25 absolute per factor): <= 2 (+ 2^-22 absolute);
+// rounding of c~_8 to f32: 1; accumulation inside the MFMAs: measured <= 3.2 on cancellation-heavy operands
+// (scripts/ubench/mfma_f16_numerics.hip), budgeted 32.  Total 48 u (+ 2^-20 absolute) = eta.  den2 needs far less: it
+// only has to be an upper bound good to ~2^-10 relative (it moves the threshold, not the residual); beta = 2^-17 T~ +
+// 2^-20 (T~ the same kind of bound for the quadratic form; measured worst 14 x 2^-24 T~) is added to its constant term,
+// which is then rounded UP to f16.  With thi = thr2 (1 + 2^-16):
+//   r = (thi den2~ + beta) + 2 eta |d~| - d~^2 < 0   =>   (|d| - eta)^2 > thr2 (1 + 2^-17) den2   =>   sure outlier
+// (the three f32 roundings of r move it by < 2^-21 relative, inside the 2^-16).  Everything else -- the survivors'
+// complete f32 filter (tier 1b), the f64 filter and the exact evaluation (tier 2) -- is score_kernel<kFund>'s, verbatim.
+//
+// Layout.  A workgroup = 4 waves = 256 models; a wave owns 64 models = 2 column blocks of 32 (B operands, 24 VGPRs,
+// plus the 2 x 16 accumulator-initial-value registers) for the whole kernel and walks chunks of 512 correspondences
+// whose split features sit in LDS as four planes of 16 B per point (A operands: lanes 0-31 read plane 0/2, lanes
+// 32-63 plane 1/3 of their row: conflict-free ds_read_b128).  In the 32x32 accumulator layout a lane holds 16
+// correspondences of ONE model (column = lane & 31), so the per-model constants stay per-lane registers and the sign
+// bits of 2 row blocks x 16 registers form the 32-bit survivor string of that (lane, column block).
+
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+#ifndef VO_SCORE_MF_ABLATE
+#define VO_SCORE_MF_ABLATE 0            // timing experiments only (scripts/mf_variants.sh); anything but 0 gives wrong counts
+#endif
+#ifdef VO_SCORE_MF_PROF                  // wave-time per phase (s_memtime ticks) into g_stats[0..5]: scripts/diag/mf_phases.py
+#define MF_T(var) const long long var = __builtin_amdgcn_s_memtime()
+#define MF_ACC(slot, t0, t1) prof[slot] += (t1) - (t0)
+#else
+#define MF_T(var)
+#define MF_ACC(slot, t0, t1)
+#endif
+#ifndef VO_SCORE_MF_CHUNK
+#define VO_SCORE_MF_CHUNK 256
+#endif
+#ifndef VO_SCORE_MF_WAVES
+#define VO_SCORE_MF_WAVES 4             // waves per SIMD the register budget must allow
+#endif
+constexpr int kMfChunk = VO_SCORE_MF_CHUNK;
+constexpr int kMfEtaUnits = 48;
+
+struct MfModel {
+    v8h ch, cl, c8, s0, s1;    // B operands: d coefficients hi / lo, (c~_8 hi, lo, 0...) against the A vector (1, 1, 0...);
+    float eta2;                // den2 entries for lane halves 0 / 1; 2 eta
+};
+
+// v ~ hi + lo.  The hi half goes through an opaque register: the compiler otherwise converts it twice, by two different
+// instruction sequences (v_cvt_pk_f16_f32 of the rounded f32 product for the stored half, v_fma_mixlo_f16 of the factors
+// for the one the residual is taken against), which disagree at near-ties -- lo then belongs to another hi.
+__device__ __forceinline__ _Float16 mf_opaque(_Float16 h)
+{
+    uint32_t bits = (uint32_t)__builtin_bit_cast(uint16_t, h);
+    asm volatile("" : "+v"(bits));
+    return __builtin_bit_cast(_Float16, (uint16_t)bits);
+}
+
+__device__ __forceinline__ void mf_split(double v, _Float16& hi, _Float16& lo)
+{
+    hi = mf_opaque((_Float16)v);
+    lo = (_Float16)(v - (double)hi);
+}
+
+__device__ __forceinline__ void mf_split(float v, _Float16& hi, _Float16& lo)
+{
+    hi = mf_opaque((_Float16)v);
+    lo = (_Float16)(v - (float)hi);          // exact in f32
+}
+
+// Per-model constants of the MFMA tier.  A model (or threshold) outside the tier's domain gets s = 1, d = 0: every
+// evaluation "survives" and is decided by the scalar tiers.  A slot past the end of the list gets d = 2^40: never survives.
+__device__ __forceinline__ void mf_model_setup(const double* F, bool live, float thr2, double Q1, double Q2, double P1, double P2,
+                                               MfModel& o)
+{
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { o.ch[k] = 0; o.cl[k] = 0; o.c8[k] = 0; o.s0[k] = 0; o.s1[k] = 0; }
+    o.eta2 = 0.f;
+    if (!live) { o.c8[0] = (_Float16)32768.f; return; }       // d = 2^15, s = 0: r = -2^30
+    double fm = 0., nanprobe = 0.;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { fm = fmax(fm, fabs(F[k])); nanprobe += F[k] * 0.; }
+    bool ok = fm > 0x1p-300 && fm < 0x1p300 && thr2 >= 0x1p-60f && thr2 <= 0x1p40f && nanprobe == 0.;
+    int e = 0;
+    (void)frexp(ok ? fm : 1., &e);
+    const double sigma = ldexp(1., -e);
+    double Fs[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Fs[k] = ok ? F[k] * sigma : 0.;
+    const double up = 1. + 0x1p-40;
+    const double r1 = Q1 / P1 * up, r2 = Q2 / P2 * up;                 // in [0.5, 1]: bounds of the scaled coordinates
+    const double pk[8] = {P2 * P1, P2 * P1, P2, P2 * P1, P2 * P1, P2, P1, P1};
+    const double bk[8] = {r2 * r1, r2 * r1, r2, r2 * r1, r2 * r1, r2, r1, r1};
+    double ck[8], cm = fabs(Fs[8]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ck[k] = Fs[k] * pk[k]; cm = fmax(cm, fabs(ck[k])); }
+    int ec = 0;
+    (void)frexp(ok ? cm : 1., &ec);                                   // cm < 2^ec
+    const double thi = (double)thr2 * (1. + 0x1p-16);
+    const double P11 = P1 * P1;
+    double G[5] = {(Fs[0] * Fs[0] + Fs[3] * Fs[3]) * P11, 2. * (Fs[0] * Fs[1] + Fs[3] * Fs[4]) * P11,
+                   (Fs[1] * Fs[1] + Fs[4] * Fs[4]) * P11, 2. * (Fs[0] * Fs[2] + Fs[3] * Fs[5]) * P1,
+                   2. * (Fs[1] * Fs[2] + Fs[4] * Fs[5]) * P1};
+    const double bs[5] = {r1 * r1, r1 * r1, r1 * r1, r1, r1};
+    double g1 = (Fs[2] * Fs[2] + Fs[5] * Fs[5]) * thi, T = g1, gm = 0.;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { G[k] *= thi; T += fabs(G[k]) * bs[k]; gm = fmax(gm, fabs(G[k])); }
+    T *= up;
+    gm = fmax(gm, g1 + 0x1p-17 * T);
+    int eg = 0;
+    (void)frexp(gm > 0. ? gm : 1., &eg);                              // gm < 2^eg
+    int ek = 14 - ec;                                                 // kappa = 2^ek: max |c~| in [2^13, 2^14)
+    if (eg + 2 * ek > 14) ek -= (eg + 2 * ek - 14 + 1) / 2;           // keep the den2 entries below 2^14 as well
+    if (ec + ek < 3 || !(gm < 0x1p600)) ok = false;                   // ... unless that costs the d coefficients their precision
+    if (!ok) { o.s1[7] = (_Float16)1.f; return; }
+    const double kap = ldexp(1., ek), kap2 = ldexp(1., 2 * ek);
+    double S = 0.;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double c = ck[k] * kap;
+        _Float16 hi, lo;
+        mf_split(c, hi, lo);
+        o.ch[k] = hi; o.cl[k] = lo;
+        S += fabs(c) * bk[k];
+    }
+    const double c8 = Fs[8] * kap;
+    S += fabs(c8);
+    {
+        _Float16 hi, lo;
+        mf_split(c8, hi, lo);
+        o.c8[0] = hi; o.c8[1] = lo;
+    }
+    const double eta = ((double)kMfEtaUnits * 0x1p-24 * S + 0x1p-20) * up;
+    o.eta2 = (float)(2. * eta * (1. + 0x1p-20));
+    _Float16 gh[5], gl[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) mf_split(G[k] * kap2, gh[k], gl[k]);
+    const double g1t = (g1 + 0x1p-17 * T) * kap2 + 0x1p-20;           // constant term + beta, rounded up to f16
+    _Float16 g1h = (_Float16)g1t;
+    if ((double)g1h < g1t) g1h = __builtin_bit_cast(_Float16, (uint16_t)(__builtin_bit_cast(uint16_t, g1h) + 1));
+    o.s0 = v8h{gh[0], gh[1], gh[2], gh[3], gh[4], gh[0], gh[1], gh[2]};
+    o.s1 = v8h{gh[3], gh[4], gl[0], gl[1], gl[2], gl[3], gl[4], g1h};
+}
+
+// Split features of one correspondence into the four A-operand planes.  (x1 y1 x2 y2) arrive scaled by exact powers of
+// two to [-1, 1]; a padding point (real = false, v = 0) gets all-zero features, the constant 1 of den2 included.
+__device__ __forceinline__ void mf_stage_point(float4 v, bool real, float iP1, float iP2, uint4& dh, uint4& dl, uint4& s0, uint4& s1)
+{
+    const float x1 = v.x * iP1, y1 = v.y * iP1, x2 = v.z * iP2, y2 = v.w * iP2;
+    const float phi[8] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1};
+    const float psi[3] = {x1 * x1, x1 * y1, y1 * y1};
+    v8h ph, pl;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        _Float16 hi, lo;
+        mf_split(phi[k], hi, lo);
+        ph[k] = hi; pl[k] = lo;
+    }
+    _Float16 sh[3], sl[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mf_split(psi[k], sh[k], sl[k]);
+    const v8h a0 = {sh[0], sh[1], sh[2], ph[6], ph[7], sl[0], sl[1], sl[2]};
+    const v8h a1 = {pl[6], pl[7], sh[0], sh[1], sh[2], ph[6], ph[7], (_Float16)(real ? 1.f : 0.f)};
+    dh = __builtin_bit_cast(uint4, ph);
+    dl = __builtin_bit_cast(uint4, pl);
+    s0 = __builtin_bit_cast(uint4, a0);
+    s1 = __builtin_bit_cast(uint4, a1);
+}
+
+// three VALU instructions per evaluation: sign(r) set <=> sure outlier
+__device__ __forceinline__ uint32_t mf_epilogue(const v16f& d, const v16f& s, float eta2, uint32_t bits)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float t = __builtin_fmaf(eta2, __builtin_fabsf(d[r]), s[r]);
+        const float rr = __builtin_fmaf(-d[r], d[r], t);
+        bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(rr), 31);
+    }
+    return bits;
+}
+
+__global__ __launch_bounds__(kThreads, VO_SCORE_MF_WAVES)
+void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
+{
+    constexpr int C = kMfChunk, kWaves = kThreads / 64;
+    constexpr int kNE = VO_SCORE_NE, kBatch = 64 * kNE;
+    constexpr int kListCap = 256, kQueueCap = 64 + kBatch;
+    static_assert(C >= kThreads, "the models' operands are staged through the feature planes");
+    __shared__ uint4 planebuf[4 * C];                       // A operands: d hi, d lo, den2 half 0, den2 half 1 (C x 16 B each);
+    uint4 (*planes)[C] = (uint4 (*)[C])planebuf;            // first the models' B operands pass through it (4 x 16 B each)
+    uint4* const stagebuf = planebuf;
+    __shared__ uint32_t wc8[kWaves][64];                    // (c~_8 hi, lo) of every model
+    __shared__ float4 spf[C];                               // the chunk's correspondences, for the scalar tiers
+    __shared__ double sscale[3][kWaves];
+    __shared__ uint16_t wlist[kWaves][kBatch + kListCap];  // tier-1b queue: (group of the chunk << 12) | (lane << 6) | bit of its survivor string
+    __shared__ uint16_t wq2[kWaves][kQueueCap];            // tier-2 queue, same entries
+    __shared__ int wcnt[kWaves][64];
+    __shared__ uint32_t wslot[kWaves][64];
+    __shared__ uint32_t wtot[kWaves], wq2n[kWaves];
+    __shared__ __attribute__((aligned(16))) float wflt[kWaves][64][12];
+
+    const int b = blockIdx.z;
+    const int n = a.n_dev ? min(a.n_dev[b], a.N) : a.N;
+    const int first = a.list && a.nstart ? a.nstart[b] : 0;
+    const int nslots = a.list ? a.nlist[b] - first : a.H;
+    const int nchunks = (n + C - 1) / C;
+    if ((int)blockIdx.y >= nchunks || (int)(blockIdx.x * kThreads) >= nslots) return;      // block-uniform
+    const float4* const pts = (const float4*)a.pts + (size_t)b * a.N;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, kh = lane >> 5, col = lane & 31;
+
+    // this thread's model: the loads go out first, the bounds pass below covers their latency
+    const int t = blockIdx.x * kThreads + threadIdx.x;
+    int slot = t;
+    bool live = t < nslots;
+    if (a.list) slot = live ? a.list[(size_t)b * a.H + first + t] : 0;
+    const size_t gslot = (size_t)b * a.H + slot;
+    if (!a.list) live = live && (!a.valid || a.valid[gslot]);
+    double M[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) M[k] = live ? a.models[gslot * 9 + k] : 0.;
+    // the first chunk's correspondences, two per thread, on their way while the models are set up
+    constexpr int kPer = (C + kThreads - 1) / kThreads;     // correspondences of a chunk per thread
+    const auto fetch = [&](int c, float4 (&v)[kPer]) {
+        const int p0 = c * C, np = min(C, n - p0);
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int i = threadIdx.x + u * kThreads;
+            v[u] = i < np ? pts[p0 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    float4 nxt[kPer];
+    fetch(blockIdx.y, nxt);
+
+    // problem-wide bounds on max(|x|,|y|,1) of either image (the models' constants are set up once for all chunks);
+    // f32 maxima of f32 values are exact, four loads in flight per thread
+    {
+        float q1 = 1.f, q2 = 1.f;
+        bool tame = true;
+        for (int i = threadIdx.x; i < n; i += 4 * kThreads) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = i + u * kThreads < n ? pts[i + u * kThreads] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                q1 = fmaxf(q1, fmaxf(fabsf(v[u].x), fabsf(v[u].y)));      // a NaN is dropped here and caught by `tame`
+                q2 = fmaxf(q2, fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+                tame = tame && fabsf(v[u].x) <= 0x1p20f && fabsf(v[u].y) <= 0x1p20f && fabsf(v[u].z) <= 0x1p20f && fabsf(v[u].w) <= 0x1p20f;
+            }
+        }
+        for (int o = 32; o; o >>= 1) {
+            q1 = fmaxf(q1, __shfl_xor(q1, o));
+            q2 = fmaxf(q2, __shfl_xor(q2, o));
+        }
+        tame = __all(tame);
+        if (lane == 0) { sscale[0][w] = (double)q1; sscale[1][w] = (double)q2; sscale[2][w] = tame ? 1. : 0.; }
+    }
+    __syncthreads();
+    double p1 = sscale[0][0], p2 = sscale[1][0], tame_all = sscale[2][0];
+#pragma unroll
+    for (int q = 1; q < kWaves; ++q) {
+        p1 = fmax(p1, sscale[0][q]);
+        p2 = fmax(p2, sscale[1][q]);
+        tame_all = fmin(tame_all, sscale[2][q]);
+    }
+    const bool fast = tame_all != 0.;                       // workgroup-uniform
+    int e1 = 0, e2 = 0;
+    (void)frexp(p1, &e1);
+    (void)frexp(p2, &e2);
+    const double P1 = ldexp(1., e1), P2 = ldexp(1., e2);   // powers of two >= the bounds
+    const float iP1 = (float)ldexp(1., -e1), iP2 = (float)ldexp(1., -e2);
+
+    // per-model constants: the scalar tiers' f32 filter (LDS, read by whichever lane works a queued pair) and the MFMA
+    // tier's B operands (staged through the feature planes, which nothing has written yet)
+    float tlo, thi;                                         // functions of the threshold alone
+    {
+        FundFilter32 f32;
+        f32 = fund_filter32_setup(M, a.thr2, p1, p2);
+        float4* o = (float4*)wflt[w][lane];
+        o[0] = make_float4(f32.F[0], f32.F[1], f32.F[2], f32.F[3]);
+        o[1] = make_float4(f32.F[4], f32.F[5], f32.F[6], f32.F[7]);
+        o[2] = make_float4(f32.F[8], f32.eta2, f32.c, 0.f);     // [11] becomes the MFMA tier's 2 eta below
+        wcnt[w][lane] = 0;
+        wslot[w][lane] = (uint32_t)gslot;
+        if (lane == 0) { wtot[w] = 0; wq2n[w] = 0; }
+        if (fast) {
+            MfModel mm;
+            mf_model_setup(M, live, a.thr2, p1, p2, P1, P2, mm);
+            uint4* st = &stagebuf[(size_t)threadIdx.x * 4];
+            st[0] = __builtin_bit_cast(uint4, mm.ch);
+            st[1] = __builtin_bit_cast(uint4, mm.cl);
+            st[2] = __builtin_bit_cast(uint4, mm.s0);
+            st[3] = __builtin_bit_cast(uint4, mm.s1);
+            wc8[w][lane] = __builtin_bit_cast(uint4, mm.c8).x;
+            wflt[w][lane][11] = mm.eta2;                    // the spare word of the scalar filter's record
+        }
+        tlo = f32.tlo; thi = f32.thi;
+    }
+    __syncthreads();
+    // (a wave past the end of the model list stays: it helps staging the chunks and keeps the barriers; its models are
+    // "never survive" columns)
+    v8h Bd0[2], Bd1[2], Bs[2];
+    float eta2r[2];
+    if (fast) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int m = 64 * w + 32 * cb + col;
+            const uint4* st = &stagebuf[(size_t)m * 4];
+            Bd0[cb] = __builtin_bit_cast(v8h, st[0]);
+            // lanes 0-31: lo halves against phi hi; 32-63: c~_8 against (1, 1, 0...)
+            Bd1[cb] = __builtin_bit_cast(v8h, kh ? make_uint4(wc8[w][32 * cb + col], 0u, 0u, 0u) : st[1]);
+            Bs[cb] = __builtin_bit_cast(v8h, st[2 + kh]);
+            eta2r[cb] = wflt[w][32 * cb + col][11];
+        }
+    }
+
+    const auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    // the scalar tiers of score_kernel<kFund>, with the model of a queued pair looked up by its index in the wave
+    const auto load_filter = [&](int m) {
+        FundFilter32 g;
+        const float4* fm = (const float4*)wflt[w][m];
+        const float4 A = fm[0], B = fm[1], Cc = fm[2];
+        g.F[0] = A.x; g.F[1] = A.y; g.F[2] = A.z; g.F[3] = A.w; g.F[4] = B.x; g.F[5] = B.y; g.F[6] = B.z; g.F[7] = B.w;
+        g.F[8] = Cc.x; g.eta2 = Cc.y; g.c = Cc.z;
+        g.thi = thi; g.tlo = tlo;
+        return g;
+    };
+    const auto flush2 = [&](uint32_t take, uint32_t base) {
+        if ((uint32_t)lane < take) {
+            const uint32_t ent = wq2[w][base + lane];
+            const int m = ent >> 9, i = ent & 511;
+            const float4 v = spf[i];
+            if (fund_decide64(a.models + (size_t)wslot[w][m] * 9, v.x, v.y, v.z, v.w, a.thr2, p1, p2)) atomicAdd(&wcnt[w][m], 1);
+#ifdef VO_SCORE_STATS
+            atomicAdd(&g_stats[2], 1ull);
+#endif
+        }
+    };
+    const auto flush1 = [&](uint32_t take, uint32_t base) {
+        bool has[kNE];
+        uint32_t ent[kNE];
+#pragma unroll
+        for (int j = 0; j < kNE; ++j) {
+            has[j] = (uint32_t)(lane + 64 * j) < take;
+            const uint32_t raw = has[j] ? wlist[w][base + lane + 64 * j] : 0u;
+            // (group, lane, bit) -> (model of the wave << 9) | correspondence of the chunk
+            const int bit = raw & 63, sl = (raw >> 6) & 63, nn = 31 - (bit & 31);
+            const int m = 32 * (1 - (bit >> 5)) + (sl & 31);
+            const int pt = 64 * (int)(raw >> 12) + 32 * (nn >> 4) + 8 * ((nn & 15) >> 2) + 4 * (sl >> 5) + (nn & 3);
+            ent[j] = (uint32_t)((m << 9) | pt);
+        }
+        int verdict[kNE];
+#pragma unroll
+        for (int j = 0; j < kNE; ++j) {
+            const FundFilter32 g = load_filter(ent[j] >> 9);
+            const float4 v = spf[ent[j] & 511];
+            verdict[j] = fund_filter32(g, v.x, v.y, v.z, v.w);
+        }
+#pragma unroll
+        for (int j = 0; j < kNE; ++j) {
+            if (has[j]) {
+                const int m = ent[j] >> 9;
+                if (verdict[j] > 0) atomicAdd(&wcnt[w][m], 1);
+                else if (verdict[j] == 0) wq2[w][atomicAdd(&wq2n[w], 1u)] = (uint16_t)ent[j];
+            }
+        }
+#ifdef VO_SCORE_STATS
+        if (lane == 0) atomicAdd(&g_stats[1], 1ull);
+#endif
+    };
+    const auto drain2 = [&](uint32_t keep) {
+        uint32_t queued = __builtin_amdgcn_readfirstlane(lds_load(&wq2n[w]));
+        if (queued > keep) {
+            do {
+                const uint32_t take = min(queued, 64u);
+                queued -= take;
+                flush2(take, queued);
+            } while (queued > keep);
+            wave_sync();
+            if (lane == 0) wq2n[w] = queued;
+            wave_sync();
+        }
+    };
+    // survivor bit k of a (lane, column block) string over one group of 64 correspondences: evaluation n = 31 - k in
+    // issue order = row block n >> 4, accumulator register n & 15
+    const auto point_of = [&](int n) { return 32 * (n >> 4) + 8 * ((n & 15) >> 2) + 4 * kh + (n & 3); };
+
+#ifdef VO_SCORE_MF_PROF
+    long long prof[6] = {0, 0, 0, 0, 0, 0};
+    const long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
+    for (int c = blockIdx.y; c < nchunks; c += gy) {
+        const int p0 = c * C, np = min(C, n - p0);
+        MF_T(ts0);
+        __syncthreads();                                     // the previous chunk (or the model staging) has been read
+        {
+            const int npad = (np + 63) & ~63;
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int i = threadIdx.x + u * kThreads;
+                if (i < npad) {
+                    spf[i] = nxt[u];
+                    if (fast) mf_stage_point(nxt[u], i < np, iP1, iP2, planes[0][i], planes[1][i], planes[2][i], planes[3][i]);
+                }
+            }
+        }
+        __syncthreads();
+        if (c + gy < nchunks) fetch(c + gy, nxt);            // the next chunk's loads fly under this chunk's work
+        MF_T(ts1);
+        MF_ACC(0, ts0, ts1);
+        if (!fast) {
+            // a problem with non-finite or huge coordinates: the owner lane's compare-form filter, then tier 2 by the owner
+            int cnt = 0;
+            const FundFilter32 f32 = load_filter(lane);
+            for (int i0 = 0; i0 < np; i0 += 32) {
+                const int nb = min(32, np - i0);
+                uint32_t bits = 0;
+#pragma unroll 1
+                for (int k = 0; k < nb; ++k) {
+                    const float4 v = spf[i0 + k];
+                    const int verdict = fund_filter32(f32, v.x, v.y, v.z, v.w);
+                    cnt += verdict > 0;
+                    bits = (bits << 1) | (uint32_t)(verdict == 0);
+                }
+                if (!live) bits = 0;
+                while (__any(bits != 0)) {
+                    if (bits) {
+                        const int pos = 31 - __clz(bits);
+                        bits &= ~(1u << pos);
+                        const float4 v = spf[i0 + nb - 1 - pos];
+                        cnt += fund_decide64(a.models + gslot * 9, v.x, v.y, v.z, v.w, a.thr2, p1, p2);
+                    }
+                }
+            }
+            if (live && cnt) atomicAdd(&wcnt[w][lane], cnt);
+            continue;
+        }
+
+        const int ngroups = (np + 63) >> 6;
+        uint32_t q1 = 0;                                     // wave-uniform: entries waiting in the tier-1b queue
+        const v16f zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#if VO_SCORE_MF_ABLATE == 2
+        if (gy != 12345) continue;                           // timing experiment: set-up and staging only
+#endif
+        for (int g = 0; g < ngroups; ++g) {
+            const int i0 = 64 * g;
+            MF_T(ta0);
+            v8h ad[2], as[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                ad[h] = __builtin_bit_cast(v8h, planes[kh][i0 + 32 * h + col]);
+                as[h] = __builtin_bit_cast(v8h, planes[2 + kh][i0 + 32 * h + col]);
+            }
+            uint32_t bits[2] = {0u, 0u};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                   // tile q of the group: row block q >> 1, column block q & 1
+                const int h = q >> 1, cb = q & 1;
+                // second K step of d: lanes 0-31 pair phi hi with the lo coefficients, lanes 32-63 pair (1, 1, 0...) with c~_8
+                const uint4 adw = __builtin_bit_cast(uint4, ad[h]);
+                const v8h a1 = __builtin_bit_cast(v8h, make_uint4(kh ? 0x3c003c00u : adw.x, kh ? 0u : adw.y, kh ? 0u : adw.z, kh ? 0u : adw.w));
+                v16f accd = __builtin_amdgcn_mfma_f32_32x32x16_f16(ad[h], Bd0[cb], zero16, 0, 0, 0);
+                accd = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, Bd1[cb], accd, 0, 0, 0);
+                const v16f accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[h], Bs[cb], zero16, 0, 0, 0);
+#if VO_SCORE_MF_ABLATE == 3
+                bits[cb] |= ~(__float_as_uint(accd[0]) & __float_as_uint(accs[5]) & 1u);   // timing experiment: MFMAs without their epilogue
+#else
+                bits[cb] = mf_epilogue(accd, accs, eta2r[cb], bits[cb]);
+#endif
+            }
+            unsigned long long cand = ~(((unsigned long long)bits[0] << 32) | bits[1]);   // bit 32 (1 - cb) + 31 - n
+#if VO_SCORE_MF_ABLATE == 1
+            if (cand != 0x123456789ull) cand = 0;            // timing experiment: tier 1a only (wrong counts)
+#endif
+            if (i0 + 64 > np) {                              // ragged end of the chunk: padding points decide nothing
+                uint32_t okm = 0;
+#pragma unroll 1
+                for (int nn = 0; nn < 32; ++nn) okm = (okm << 1) | (uint32_t)(i0 + point_of(nn) < np);
+                cand &= ((unsigned long long)okm << 32) | okm;
+            }
+            MF_T(ta1);
+            MF_ACC(1, ta0, ta1);
+            uint32_t at = atomicAdd(&wtot[w], (uint32_t)__popcll(cand));
+            wave_sync();
+            const uint32_t q1new = __builtin_amdgcn_readfirstlane(lds_load(&wtot[w]));
+#ifdef VO_SCORE_STATS
+            atomicAdd(&g_stats[0], (unsigned long long)__popcll(cand));
+            if (lane == 0) atomicAdd(&g_stats[3], 1ull);
+#endif
+            if (q1new - q1 <= (uint32_t)kListCap) {
+                // raw entries (group << 12) | (lane << 6) | bit: this loop runs as long as the wave's busiest lane has
+                // survivors, so it only finds and stores; flush1 decodes (there every lane has work)
+                uint32_t c0 = (uint32_t)(cand >> 32), c1 = (uint32_t)cand;
+                const uint32_t tag = (uint32_t)(g << 12) | (uint32_t)(lane << 6);
+                while (c0) {
+                    wlist[w][at++] = (uint16_t)(tag | 32u | (uint32_t)__builtin_ctz(c0));
+                    c0 &= c0 - 1;
+                }
+                while (c1) {
+                    wlist[w][at++] = (uint16_t)(tag | (uint32_t)__builtin_ctz(c1));
+                    c1 &= c1 - 1;
+                }
+                q1 = q1new;
+                wave_sync();
+                MF_T(tb1);
+                MF_ACC(2, ta1, tb1);
+                if (q1 >= (uint32_t)kBatch) {
+                    do {
+                        q1 -= kBatch;
+                        MF_T(tc0);
+                        flush1(kBatch, q1);
+                        wave_sync();
+                        MF_T(tc1);
+                        MF_ACC(3, tc0, tc1);
+                        drain2(63);
+                        MF_T(tc2);
+                        MF_ACC(4, tc1, tc2);
+                    } while (q1 >= (uint32_t)kBatch);
+                    if (lane == 0) wtot[w] = q1;
+                    wave_sync();
+                }
+            } else {
+                // more survivors in one group than the queue has room for: every lane works its own strings off
+                wave_sync();
+                if (lane == 0) wtot[w] = q1;
+                wave_sync();
+                while (__any(cand != 0)) {
+                    if (cand) {
+                        const int bit = __ffsll((long long)cand) - 1;
+                        cand &= cand - 1;
+                        const int m = 32 * (1 - (bit >> 5)) + col;
+                        const float4 v = spf[i0 + point_of(31 - (bit & 31))];
+                        const FundFilter32 gf = load_filter(m);
+                        int verdict = fund_filter32(gf, v.x, v.y, v.z, v.w);
+                        if (verdict == 0)
+                            verdict = fund_decide64(a.models + (size_t)wslot[w][m] * 9, v.x, v.y, v.z, v.w, a.thr2, p1, p2) ? 1 : -1;
+                        if (verdict > 0) atomicAdd(&wcnt[w][m], 1);
+                    }
+                }
+            }
+        }
+        // the queues index this chunk's correspondences: empty them before the next chunk is staged
+        MF_T(te0);
+        wave_sync();
+        if (q1) flush1(q1, 0);
+        wave_sync();
+        if (lane == 0) wtot[w] = 0;
+        drain2(0);
+        wave_sync();
+        MF_T(te1);
+        MF_ACC(5, te0, te1);
+    }
+#ifdef VO_SCORE_MF_PROF
+    if (lane == 0) {
+        for (int k = 0; k < 6; ++k) atomicAdd(&g_stats[k], (unsigned long long)prof[k]);
+        atomicAdd(&g_stats[6], (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));
+        atomicAdd(&g_stats[7], 1ull);
+    }
+#endif
+    wave_sync();
+    const int cnt = lds_load(&wcnt[w][lane]);
+    if (live && cnt) atomicAdd(a.counts + gslot, cnt);
+}
