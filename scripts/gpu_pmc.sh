@@ -11,7 +11,7 @@ import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
-    short = "knn2" if "knn2_partial" in k else "score<0>" if "score_kernel<0>" in k else "score<2>" if "score_kernel<2>" in k else "solve_7pt" if "solve_7pt" in k else "solve_p3p" if "solve_p3p" in k else None
+    short = "knn2" if "knn2_partial" in k else "score<0>" if ("score_kernel<0>" in k or "score_fund_mfma" in k) else "score<2>" if "score_kernel<2>" in k else "solve_7pt" if "solve_7pt" in k else "solve_p3p" if "solve_p3p" in k else None
     if not short: continue
     acc[short][r["Counter_Name"]] += float(r["Counter_Value"])
     n[(short, r["Counter_Name"])] += 1

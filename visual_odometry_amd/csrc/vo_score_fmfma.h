@@ -181,6 +181,19 @@ __device__ __forceinline__ void mf_stage_point(float4 v, bool real, float iP1, f
     s1 = __builtin_bit_cast(uint4, a1);
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave in registers (DPP row shifts, then the row totals broadcast across
+// rows): the queue positions of a group's survivors without an LDS round trip.
+__device__ __forceinline__ uint32_t mf_wave_scan(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);     // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);     // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);     // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);     // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2, 3
+    return x;
+}
+
 // three VALU instructions per evaluation: sign(r) set <=> sure outlier
 __device__ __forceinline__ uint32_t mf_epilogue(const v16f& d, const v16f& s, float eta2, uint32_t bits)
 {
@@ -210,7 +223,6 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
     __shared__ uint16_t wq2[kWaves][kQueueCap];            // tier-2 queue, same entries
     __shared__ int wcnt[kWaves][64];
     __shared__ uint32_t wslot[kWaves][64];
-    __shared__ uint32_t wtot[kWaves], wq2n[kWaves];
     __shared__ __attribute__((aligned(16))) float wflt[kWaves][64][12];
 
     const int b = blockIdx.z;
@@ -295,7 +307,6 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
         o[2] = make_float4(f32.F[8], f32.eta2, f32.c, 0.f);     // [11] becomes the MFMA tier's 2 eta below
         wcnt[w][lane] = 0;
         wslot[w][lane] = (uint32_t)gslot;
-        if (lane == 0) { wtot[w] = 0; wq2n[w] = 0; }
         if (fast) {
             MfModel mm;
             mf_model_setup(M, live, a.thr2, p1, p2, P1, P2, mm);
@@ -338,6 +349,7 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
         g.thi = thi; g.tlo = tlo;
         return g;
     };
+    uint32_t q2 = 0;                                         // wave-uniform: entries waiting in the tier-2 queue
     const auto flush2 = [&](uint32_t take, uint32_t base) {
         if ((uint32_t)lane < take) {
             const uint32_t ent = wq2[w][base + lane];
@@ -371,26 +383,24 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
         }
 #pragma unroll
         for (int j = 0; j < kNE; ++j) {
-            if (has[j]) {
-                const int m = ent[j] >> 9;
-                if (verdict[j] > 0) atomicAdd(&wcnt[w][m], 1);
-                else if (verdict[j] == 0) wq2[w][atomicAdd(&wq2n[w], 1u)] = (uint16_t)ent[j];
-            }
+            const bool undecided = has[j] && verdict[j] == 0;
+            const unsigned long long um = __ballot(undecided);               // tier-2 queue positions from the ballot: no LDS counter
+            if (has[j] && verdict[j] > 0) atomicAdd(&wcnt[w][ent[j] >> 9], 1);
+            if (undecided) wq2[w][q2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(um >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)um, 0u))] = (uint16_t)ent[j];
+            q2 += (uint32_t)__popcll(um);
         }
 #ifdef VO_SCORE_STATS
         if (lane == 0) atomicAdd(&g_stats[1], 1ull);
 #endif
     };
     const auto drain2 = [&](uint32_t keep) {
-        uint32_t queued = __builtin_amdgcn_readfirstlane(lds_load(&wq2n[w]));
-        if (queued > keep) {
-            do {
-                const uint32_t take = min(queued, 64u);
-                queued -= take;
-                flush2(take, queued);
-            } while (queued > keep);
+        if (q2 > keep) {
             wave_sync();
-            if (lane == 0) wq2n[w] = queued;
+            do {
+                const uint32_t take = min(q2, 64u);
+                q2 -= take;
+                flush2(take, q2);
+            } while (q2 > keep);
             wave_sync();
         }
     };
@@ -492,9 +502,9 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
             }
             MF_T(ta1);
             MF_ACC(1, ta0, ta1);
-            uint32_t at = atomicAdd(&wtot[w], (uint32_t)__popcll(cand));
-            wave_sync();
-            const uint32_t q1new = __builtin_amdgcn_readfirstlane(lds_load(&wtot[w]));
+            const uint32_t mine = (uint32_t)__popcll(cand), incl = mf_wave_scan(mine);
+            uint32_t at = q1 + incl - mine;                  // this lane's place in the queue
+            const uint32_t q1new = q1 + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 #ifdef VO_SCORE_STATS
             atomicAdd(&g_stats[0], (unsigned long long)__popcll(cand));
             if (lane == 0) atomicAdd(&g_stats[3], 1ull);
@@ -528,14 +538,9 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
                         MF_T(tc2);
                         MF_ACC(4, tc1, tc2);
                     } while (q1 >= (uint32_t)kBatch);
-                    if (lane == 0) wtot[w] = q1;
-                    wave_sync();
                 }
             } else {
                 // more survivors in one group than the queue has room for: every lane works its own strings off
-                wave_sync();
-                if (lane == 0) wtot[w] = q1;
-                wave_sync();
                 while (__any(cand != 0)) {
                     if (cand) {
                         const int bit = __ffsll((long long)cand) - 1;
@@ -556,7 +561,6 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
         wave_sync();
         if (q1) flush1(q1, 0);
         wave_sync();
-        if (lane == 0) wtot[w] = 0;
         drain2(0);
         wave_sync();
         MF_T(te1);
