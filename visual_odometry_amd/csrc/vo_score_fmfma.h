@@ -57,7 +57,7 @@ constexpr int kMfEtaUnits = 48;
 
 struct MfModel {
     v8h ch, cl, c8, s0, s1;    // B operands: d coefficients hi / lo, (c~_8 hi, lo, 0...) against the A vector (1, 1, 0...);
-    float eta2;                // den2 entries for lane halves 0 / 1; 2 eta
+                               // den2 entries for lane halves 0 / 1
 };
 
 // v ~ hi + lo.  The hi half goes through an opaque register: the compiler otherwise converts it twice, by two different
@@ -89,7 +89,6 @@ __device__ __forceinline__ void mf_model_setup(const double* F, bool live, float
 {
 #pragma unroll
     for (int k = 0; k < 8; ++k) { o.ch[k] = 0; o.cl[k] = 0; o.c8[k] = 0; o.s0[k] = 0; o.s1[k] = 0; }
-    o.eta2 = 0.f;
     if (!live) { o.c8[0] = (_Float16)32768.f; return; }       // d = 2^15, s = 0: r = -2^30
     double fm = 0., nanprobe = 0.;
 #pragma unroll
@@ -118,14 +117,29 @@ __device__ __forceinline__ void mf_model_setup(const double* F, bool live, float
     const double bs[5] = {r1 * r1, r1 * r1, r1 * r1, r1, r1};
     double g1 = (Fs[2] * Fs[2] + Fs[5] * Fs[5]) * thi, T = g1, gm = 0.;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) { G[k] *= thi; T += fabs(G[k]) * bs[k]; gm = fmax(gm, fabs(G[k])); }
+    for (int k = 0; k < 5; ++k) { G[k] *= thi; T += fabs(G[k]) * bs[k]; }
     T *= up;
-    gm = fmax(gm, g1 + 0x1p-17 * T);
+    // The margin 2 eta |d| of (|d| - eta)^2 is traded for a scaling of the threshold side (one FMA less per
+    // evaluation): 2 eta |d| <= dl d^2 + eta^2 / dl, so (|d| - eta)^2 >= (1 - dl) d^2 - eta^2 (1/dl - 1), and
+    //   d~^2 > (thi den2~ + beta + eta^2 (1/dl - 1)) / (1 - dl)   =>   sure outlier.
+    // With dl ~ eta / (thr sqrt(den2)) the band of undecided residuals is as wide as the exact margin's; den2 varies
+    // over the correspondences, so dl is set from a typical value (a quarter of the bound T~), clamped to [2^-6, 1/2].
+    double S0 = fabs(Fs[8]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) S0 += fabs(ck[k]) * bk[k];
+    const double eta0 = (double)kMfEtaUnits * 0x1p-24 * S0 * up;       // eta at kappa = 1, without its absolute floor
+    double dl = T > 0. ? eta0 / sqrt(0.25 * T) : 0.5;
+    dl = fmin(0.5, fmax(0x1p-6, dl));
+    const double fs = (1. / (1. - dl)) * up, qd = (1. / dl - 1.) * up;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { G[k] *= fs; gm = fmax(gm, fabs(G[k])); }
+    gm = fmax(gm, ((g1 + 0x1p-17 * T) + 4. * eta0 * eta0 * qd) * fs);  // (4 eta0^2 covers eta^2 with its floor, see below)
     int eg = 0;
     (void)frexp(gm > 0. ? gm : 1., &eg);                              // gm < 2^eg
     int ek = 14 - ec;                                                 // kappa = 2^ek: max |c~| in [2^13, 2^14)
     if (eg + 2 * ek > 14) ek -= (eg + 2 * ek - 14 + 1) / 2;           // keep the den2 entries below 2^14 as well
     if (ec + ek < 3 || !(gm < 0x1p600)) ok = false;                   // ... unless that costs the d coefficients their precision
+    if (!(ldexp(0x1p-20, -ek) <= eta0)) ok = false;                   // (never with |c~| >= 2^3: eta0 kappa >= 2^-18)
     if (!ok) { o.s1[7] = (_Float16)1.f; return; }
     const double kap = ldexp(1., ek), kap2 = ldexp(1., 2 * ek);
     double S = 0.;
@@ -145,11 +159,11 @@ __device__ __forceinline__ void mf_model_setup(const double* F, bool live, float
         o.c8[0] = hi; o.c8[1] = lo;
     }
     const double eta = ((double)kMfEtaUnits * 0x1p-24 * S + 0x1p-20) * up;
-    o.eta2 = (float)(2. * eta * (1. + 0x1p-20));
     _Float16 gh[5], gl[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) mf_split(G[k] * kap2, gh[k], gl[k]);
-    const double g1t = (g1 + 0x1p-17 * T) * kap2 + 0x1p-20;           // constant term + beta, rounded up to f16
+    // constant term + beta + the eta^2 term, rounded up to f16
+    const double g1t = ((g1 + 0x1p-17 * T) * kap2 + 0x1p-20 + eta * eta * qd) * fs;
     _Float16 g1h = (_Float16)g1t;
     if ((double)g1h < g1t) g1h = __builtin_bit_cast(_Float16, (uint16_t)(__builtin_bit_cast(uint16_t, g1h) + 1));
     o.s0 = v8h{gh[0], gh[1], gh[2], gh[3], gh[4], gh[0], gh[1], gh[2]};
@@ -195,12 +209,11 @@ __device__ __forceinline__ uint32_t mf_wave_scan(uint32_t x)
 }
 
 // three VALU instructions per evaluation: sign(r) set <=> sure outlier
-__device__ __forceinline__ uint32_t mf_epilogue(const v16f& d, const v16f& s, float eta2, uint32_t bits)
+__device__ __forceinline__ uint32_t mf_epilogue(const v16f& d, const v16f& s, uint32_t bits)
 {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const float t = __builtin_fmaf(eta2, __builtin_fabsf(d[r]), s[r]);
-        const float rr = __builtin_fmaf(-d[r], d[r], t);
+        const float rr = __builtin_fmaf(-d[r], d[r], s[r]);
         bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(rr), 31);
     }
     return bits;
@@ -304,7 +317,7 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
         float4* o = (float4*)wflt[w][lane];
         o[0] = make_float4(f32.F[0], f32.F[1], f32.F[2], f32.F[3]);
         o[1] = make_float4(f32.F[4], f32.F[5], f32.F[6], f32.F[7]);
-        o[2] = make_float4(f32.F[8], f32.eta2, f32.c, 0.f);     // [11] becomes the MFMA tier's 2 eta below
+        o[2] = make_float4(f32.F[8], f32.eta2, f32.c, 0.f);
         wcnt[w][lane] = 0;
         wslot[w][lane] = (uint32_t)gslot;
         if (fast) {
@@ -316,7 +329,6 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
             st[2] = __builtin_bit_cast(uint4, mm.s0);
             st[3] = __builtin_bit_cast(uint4, mm.s1);
             wc8[w][lane] = __builtin_bit_cast(uint4, mm.c8).x;
-            wflt[w][lane][11] = mm.eta2;                    // the spare word of the scalar filter's record
         }
         tlo = f32.tlo; thi = f32.thi;
     }
@@ -324,7 +336,6 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
     // (a wave past the end of the model list stays: it helps staging the chunks and keeps the barriers; its models are
     // "never survive" columns)
     v8h Bd0[2], Bd1[2], Bs[2];
-    float eta2r[2];
     if (fast) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
@@ -334,7 +345,6 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
             // lanes 0-31: lo halves against phi hi; 32-63: c~_8 against (1, 1, 0...)
             Bd1[cb] = __builtin_bit_cast(v8h, kh ? make_uint4(wc8[w][32 * cb + col], 0u, 0u, 0u) : st[1]);
             Bs[cb] = __builtin_bit_cast(v8h, st[2 + kh]);
-            eta2r[cb] = wflt[w][32 * cb + col][11];
         }
     }
 
@@ -460,6 +470,8 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
         }
 
         const int ngroups = (np + 63) >> 6;
+        uint32_t keep = kh ? 0u : ~0u, ones = kh ? 0x3c003c00u : 0u;    // lanes 32-63: (1, 1, 0...) instead of phi hi
+        asm volatile("" : "+v"(keep), "+v"(ones));
         uint32_t q1 = 0;                                     // wave-uniform: entries waiting in the tier-1b queue
         const v16f zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #if VO_SCORE_MF_ABLATE == 2
@@ -479,15 +491,15 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
             for (int q = 0; q < 4; ++q) {                   // tile q of the group: row block q >> 1, column block q & 1
                 const int h = q >> 1, cb = q & 1;
                 // second K step of d: lanes 0-31 pair phi hi with the lo coefficients, lanes 32-63 pair (1, 1, 0...) with c~_8
-                const uint4 adw = __builtin_bit_cast(uint4, ad[h]);
-                const v8h a1 = __builtin_bit_cast(v8h, make_uint4(kh ? 0x3c003c00u : adw.x, kh ? 0u : adw.y, kh ? 0u : adw.z, kh ? 0u : adw.w));
+                const uint4 adw = __builtin_bit_cast(uint4, ad[h]);       // (bit masks: a v_cndmask_b32 costs 12 cycles, a v_and_b32 2)
+                const v8h a1 = __builtin_bit_cast(v8h, make_uint4((adw.x & keep) | ones, adw.y & keep, adw.z & keep, adw.w & keep));
                 v16f accd = __builtin_amdgcn_mfma_f32_32x32x16_f16(ad[h], Bd0[cb], zero16, 0, 0, 0);
                 accd = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, Bd1[cb], accd, 0, 0, 0);
                 const v16f accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[h], Bs[cb], zero16, 0, 0, 0);
 #if VO_SCORE_MF_ABLATE == 3
                 bits[cb] |= ~(__float_as_uint(accd[0]) & __float_as_uint(accs[5]) & 1u);   // timing experiment: MFMAs without their epilogue
 #else
-                bits[cb] = mf_epilogue(accd, accs, eta2r[cb], bits[cb]);
+                bits[cb] = mf_epilogue(accd, accs, bits[cb]);
 #endif
             }
             unsigned long long cand = ~(((unsigned long long)bits[0] << 32) | bits[1]);   // bit 32 (1 - cb) + 31 - n
