@@ -380,8 +380,8 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
             const uint32_t raw = has[j] ? wlist[w][base + lane + 64 * j] : 0u;
             // (group, lane, bit) -> (model of the wave << 9) | correspondence of the chunk
             const int bit = raw & 63, sl = (raw >> 6) & 63, nn = 31 - (bit & 31);
-            const int m = 32 * (1 - (bit >> 5)) + (sl & 31);
-            const int pt = 64 * (int)(raw >> 12) + 32 * (nn >> 4) + 8 * ((nn & 15) >> 2) + 4 * (sl >> 5) + (nn & 3);
+            const int m = 32 * (nn >> 4) + 8 * ((nn & 15) >> 2) + 4 * (sl >> 5) + (nn & 3);
+            const int pt = 64 * (int)(raw >> 12) + 32 * (1 - (bit >> 5)) + (sl & 31);
             ent[j] = (uint32_t)((m << 9) | pt);
         }
         int verdict[kNE];
@@ -416,7 +416,7 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
     };
     // survivor bit k of a (lane, column block) string over one group of 64 correspondences: evaluation n = 31 - k in
     // issue order = row block n >> 4, accumulator register n & 15
-    const auto point_of = [&](int n) { return 32 * (n >> 4) + 8 * ((n & 15) >> 2) + 4 * kh + (n & 3); };
+    const auto model_at = [&](int n) { return 32 * (n >> 4) + 8 * ((n & 15) >> 2) + 4 * kh + (n & 3); };
 
 #ifdef VO_SCORE_MF_PROF
     long long prof[6] = {0, 0, 0, 0, 0, 0};
@@ -493,25 +493,24 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
                 // second K step of d: lanes 0-31 pair phi hi with the lo coefficients, lanes 32-63 pair (1, 1, 0...) with c~_8
                 const uint4 adw = __builtin_bit_cast(uint4, ad[h]);       // (bit masks: a v_cndmask_b32 costs 12 cycles, a v_and_b32 2)
                 const v8h a1 = __builtin_bit_cast(v8h, make_uint4((adw.x & keep) | ones, adw.y & keep, adw.z & keep, adw.w & keep));
-                v16f accd = __builtin_amdgcn_mfma_f32_32x32x16_f16(ad[h], Bd0[cb], zero16, 0, 0, 0);
-                accd = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, Bd1[cb], accd, 0, 0, 0);
-                const v16f accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[h], Bs[cb], zero16, 0, 0, 0);
+                // models along the rows, correspondences along the columns: a lane's 16 accumulators are 16 MODELS for
+                // one correspondence (column = lane & 31), which spreads the survivors of a good model over the lanes
+                v16f accd = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bd0[cb], ad[h], zero16, 0, 0, 0);
+                accd = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bd1[cb], a1, accd, 0, 0, 0);
+                const v16f accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bs[cb], as[h], zero16, 0, 0, 0);
 #if VO_SCORE_MF_ABLATE == 3
-                bits[cb] |= ~(__float_as_uint(accd[0]) & __float_as_uint(accs[5]) & 1u);   // timing experiment: MFMAs without their epilogue
+                bits[h] |= ~(__float_as_uint(accd[0]) & __float_as_uint(accs[5]) & 1u);   // timing experiment: MFMAs without their epilogue
 #else
-                bits[cb] = mf_epilogue(accd, accs, bits[cb]);
+                bits[h] = mf_epilogue(accd, accs, bits[h]);
 #endif
             }
-            unsigned long long cand = ~(((unsigned long long)bits[0] << 32) | bits[1]);   // bit 32 (1 - cb) + 31 - n
+            // bit 32 (1 - h) + 31 - n: correspondence i0 + 32 h + column, model 32 cb + row of accumulator r, n = 16 cb + r
+            unsigned long long cand = ~(((unsigned long long)bits[0] << 32) | bits[1]);
 #if VO_SCORE_MF_ABLATE == 1
             if (cand != 0x123456789ull) cand = 0;            // timing experiment: tier 1a only (wrong counts)
 #endif
-            if (i0 + 64 > np) {                              // ragged end of the chunk: padding points decide nothing
-                uint32_t okm = 0;
-#pragma unroll 1
-                for (int nn = 0; nn < 32; ++nn) okm = (okm << 1) | (uint32_t)(i0 + point_of(nn) < np);
-                cand &= ((unsigned long long)okm << 32) | okm;
-            }
+            if (i0 + 64 > np)                                // ragged end of the chunk: padding points decide nothing
+                cand &= (i0 + col < np ? 0xffffffff00000000ull : 0ull) | (i0 + 32 + col < np ? 0xffffffffull : 0ull);
             MF_T(ta1);
             MF_ACC(1, ta0, ta1);
             const uint32_t mine = (uint32_t)__popcll(cand), incl = mf_wave_scan(mine);
@@ -536,6 +535,9 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
                 }
                 q1 = q1new;
                 wave_sync();
+#if VO_SCORE_MF_ABLATE == 4
+                if (gy != 12345) q1 = 0;                     // timing experiment: survivors are queued, then dropped
+#endif
                 MF_T(tb1);
                 MF_ACC(2, ta1, tb1);
                 if (q1 >= (uint32_t)kBatch) {
@@ -557,8 +559,8 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
                     if (cand) {
                         const int bit = __ffsll((long long)cand) - 1;
                         cand &= cand - 1;
-                        const int m = 32 * (1 - (bit >> 5)) + col;
-                        const float4 v = spf[i0 + point_of(31 - (bit & 31))];
+                        const int m = model_at(31 - (bit & 31));
+                        const float4 v = spf[i0 + 32 * (1 - (bit >> 5)) + col];
                         const FundFilter32 gf = load_filter(m);
                         int verdict = fund_filter32(gf, v.x, v.y, v.z, v.w);
                         if (verdict == 0)
