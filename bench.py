@@ -62,6 +62,7 @@ HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s HBM3E
 I8_OPS_PER_CLK_CU = 8192      # 4 SIMD x 2048 int8 ops/clk (v_mfma_i32_32x32x32_i8: 65536 ops / 32 clk)
 VALU_LANES_PER_CLK_CU = 128   # 4 SIMD-32: a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md)
 FP64_FLOP_PER_CLK_CU = 128    # 78.6 TFLOP/s f64 vector at 256 CU x 2.4 GHz
+F16_FLOP_PER_CLK_CU = 4096    # 4 SIMD x 1024 flop/clk (v_mfma_f32_32x32x16_f16: 32768 flop / 32 clk): 2.52 PFLOP/s dense
 CLOCK_GHZ = 2.4               # nominal peak clock; the chip holds less under load (profiles/r2_counters.json)
 
 
@@ -455,6 +456,33 @@ def worker(args) -> int:
         return r
 
     sf = valu_roofline(tv, "E" if ess else "F", evals_f, n_models_f, t_f, 32 if ess else 16, 72, f"score_{tv}_kernel")
+    isa_f = _load_json(f"{PROFILE_TAG}_score_fund_isa.json") or {}
+    if not ess and isa_f.get("mfma_flop_per_evaluation_useful") and evals_f:
+        # the F count kernel's first tier runs on the matrix cores (csrc/vo_score_fmfma.h): priced against the dense f16 MFMA peak
+        # with the multiply-adds the split inner products need; the VALU-issue view of the same launch is kept beside it
+        f16_peak = cus * F16_FLOP_PER_CLK_CU * CLOCK_GHZ * 1e9 / 1e12
+        useful, issued, vpe = isa_f["mfma_flop_per_evaluation_useful"], isa_f["mfma_flop_per_evaluation_issued"], isa_f["valu_per_evaluation"]
+        c = kc("score_fund_kernel")
+        sf = {"kernel": "score_fund_mfma_kernel", "bound": "mfma", "unit": "TFLOP/s", "peak": f16_peak,
+              "achieved": evals_f * useful / t_f / 1e12, "traffic": c.get("hbm_bytes_per_launch"),
+              "units_per_launch": sf["units_per_launch"], "mfma_flop_per_evaluation": useful,
+              "mfma_flop_per_evaluation_issued": issued, "valu_instructions_per_evaluation": vpe,
+              "valu_issue_frac": evals_f * vpe / t_f / 1e12 / valu_peak,
+              "effective_streaming_GBps": sf["effective_streaming_GBps"], "effective_streaming_note": sf["effective_streaming_note"]}
+        sf["frac"] = sf["achieved"] / f16_peak
+        sf["frac_of_issued_flops"] = evals_f * issued / t_f / 1e12 / f16_peak
+        sf["note"] = (f"achieved = evaluations x {useful} flop per evaluation (d = x2^T F x1 and den2 = |(F x1)_xy|^2 as inner products of f16 hi/lo "
+                      f"split coefficient and feature vectors: 26 + 16 multiply-adds; the three v_mfma_f32_32x32x16_f16 per 1024 evaluations issue "
+                      f"{issued}) / launch time; peak = {cus} CU x {F16_FLOP_PER_CLK_CU} flop/clk x {CLOCK_GHZ} GHz (dense f16 MFMA).  The VALU side of the "
+                      f"tier is {vpe} instructions per evaluation (profiles/{PROFILE_TAG}_score_fund_isa.json), valu_issue_frac of the 78.6 T "
+                      "lane-instructions/s peak.  Neither pipe is the limit any more: ~2.4 % of the evaluations are true inliers of their "
+                      "hypothesis and take the complete two-sided f32 filter through a per-wave queue (LDS gathers, latency-bound), see "
+                      "DESIGN.md 4.2; the scalar kernel this replaces needed 14.125 VALU instructions per evaluation and 1.7x the time")
+        if c.get("clock_ghz"):
+            sf["clock_ghz_under_load"] = c["clock_ghz"]
+            sf["frac_at_measured_clock"] = sf["achieved"] / (cus * F16_FLOP_PER_CLK_CU * c["clock_ghz"] * 1e9 / 1e12)
+        if c.get("SQ_INSTS_VALU") and c.get("evaluations_per_launch"):
+            sf["valu_per_evaluation_from_SQ_INSTS_VALU"] = c["SQ_INSTS_VALU"] * 64 / c["evaluations_per_launch"]
     sp = valu_roofline("pnp", "PnP", evals_p, n_models_p, t_p, 20, 96, "score_pnp_kernel")
     sp["note"] = (sp.get("note") or "") + ("; in weak mode the PnP chain runs on a side stream under the two-view chain, so these launches "
                                            "share the GPU and their durations are upper bounds (standalone: profiles/r3_score_standalone.json)")

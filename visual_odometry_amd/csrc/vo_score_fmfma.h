@@ -9,29 +9,34 @@
 // so a 32 x 32 tile of evaluations is a small GEMM.  f32 MFMA runs at the VALU's rate and would gain nothing; f16 MFMA
 // is 16x faster but f16 has 11 bits, so every factor is split into hi + lo halves (v ~ hi + lo, |v - hi - lo| <=
 // 2^-22 |v|) and the products hi*hi + hi*lo + lo*hi are laid along K (the MFMA multiplies f16 pairs exactly and sums in
-// f32).  d takes 8 x 3 = 24 K entries (two K=16 steps; the constant term c_8 enters as the accumulator's initial value,
-// in f32), den2 takes 5 x 3 + 1 = 16 (one step): three v_mfma_f32_32x32x16_f16 per 1024 evaluations, 0.094 cycles per
-// evaluation per SIMD against 0.44 for the 14 VALU instructions of the scalar form at its issue peak.  The VALU keeps
-// three instructions per evaluation (r = s + 2 eta |d| - d^2 as two FMAs, the sign bit shifted into a bit string).
+// f32).  d takes 8 x 3 + 2 = 26 K entries (two K=16 steps; the constant term c_8 = hi + lo meets a (1, 1, 0...) vector
+// in the second step's upper lane half), den2 takes 5 x 3 + 1 = 16 (one step): three v_mfma_f32_32x32x16_f16 per 1024
+// evaluations, 0.094 cycles per evaluation per SIMD against 0.44 for the 14 VALU instructions of the scalar form at its
+// issue peak.  The VALU keeps two instructions per evaluation: r = s - d^2 as one FMA, its sign bit shifted into a bit
+// string (v_alignbit_b32); sign set <=> sure outlier.
 //
-// Error budget of d (unit u = 2^-24 S~, S~ = sum_k |c~_k| B_k + |c~_8| with B_k the chunk-wide bound of |phi~_k|):
+// Error budget of d (unit u = 2^-24 S~, S~ = sum_k |c~_k| B_k + |c~_8| with B_k the problem-wide bound of |phi~_k|):
 // f32 rounding of the product features 1; the splits of features and coefficients and the dropped lo*lo product, 2^-22
 // relative each: 12; f16 subnormal quantum of the lo halves (2^-25 absolute per factor): <= 2 (+ 2^-22 absolute);
-// rounding of c~_8 to f32: 1; accumulation inside the MFMAs: measured <= 3.2 on cancellation-heavy operands
-// (scripts/ubench/mfma_f16_numerics.hip), budgeted 32.  Total 48 u (+ 2^-20 absolute) = eta.  den2 needs far less: it
-// only has to be an upper bound good to ~2^-10 relative (it moves the threshold, not the residual); beta = 2^-17 T~ +
-// 2^-20 (T~ the same kind of bound for the quadratic form; measured worst 14 x 2^-24 T~) is added to its constant term,
-// which is then rounded UP to f16.  With thi = thr2 (1 + 2^-16):
-//   r = (thi den2~ + beta) + 2 eta |d~| - d~^2 < 0   =>   (|d| - eta)^2 > thr2 (1 + 2^-17) den2   =>   sure outlier
-// (the three f32 roundings of r move it by < 2^-21 relative, inside the 2^-16).  Everything else -- the survivors'
-// complete f32 filter (tier 1b), the f64 filter and the exact evaluation (tier 2) -- is score_kernel<kFund>'s, verbatim.
+// split of c~_8: 3; accumulation inside the MFMAs: measured <= 3.2 on cancellation-heavy operands
+// (scripts/ubench/mfma_f16_numerics.hip, which also shows f16 subnormal operands are honoured), budgeted 30.  Total 48 u
+// (+ 2^-20 absolute) = eta.  den2 needs far less: it only has to be an upper bound good to ~2^-10 relative (it moves the
+// threshold, not the residual); beta = 2^-17 T~ + 2^-20 (T~ the same kind of bound for the quadratic form; measured
+// worst 14 x 2^-24 T~) is added to its constant term, which is then rounded UP to f16.  With thi = thr2 (1 + 2^-16) and
+// a per-model dl in [2^-6, 1/2] (2 eta |d| <= dl d^2 + eta^2 / dl):
+//   s = (thi den2~ + beta + eta^2 (1/dl - 1)) / (1 - dl)  <  d~^2   =>   (|d| - eta)^2 > thr2 (1 + 2^-17) den2   =>   sure outlier
+// (s comes out of the MFMA with all of that folded into its coefficients; the one f32 rounding of r = s - d~^2 moves it by
+// < 2^-23 relative, inside the 2^-16).  Everything else -- the survivors' complete f32 filter (tier 1b), the f64 filter
+// and the exact evaluation (tier 2) -- is score_kernel<kFund>'s, verbatim.  On the bench data ~2.4 % of the evaluations
+// survive, nearly all of them true inliers of their hypothesis.
 //
-// Layout.  A workgroup = 4 waves = 256 models; a wave owns 64 models = 2 column blocks of 32 (B operands, 24 VGPRs,
-// plus the 2 x 16 accumulator-initial-value registers) for the whole kernel and walks chunks of 512 correspondences
-// whose split features sit in LDS as four planes of 16 B per point (A operands: lanes 0-31 read plane 0/2, lanes
-// 32-63 plane 1/3 of their row: conflict-free ds_read_b128).  In the 32x32 accumulator layout a lane holds 16
-// correspondences of ONE model (column = lane & 31), so the per-model constants stay per-lane registers and the sign
-// bits of 2 row blocks x 16 registers form the 32-bit survivor string of that (lane, column block).
+// Layout.  A workgroup = 4 waves = 256 models; a wave owns 64 models = 2 row blocks of 32 (MFMA A operands, 24 VGPRs) for
+// the whole kernel and walks chunks of 256 correspondences whose split features sit in LDS as four planes of 16 B per
+// point (B operands: lanes 0-31 read plane 0/2, lanes 32-63 plane 1/3 of their column: conflict-free ds_read_b128).
+// Models along the rows, correspondences along the columns: a lane's 16 accumulators are 16 models for ONE
+// correspondence, so the survivors of a good model are spread over the lanes and the per-lane loops that queue them stay
+// short.  128 VGPRs and 40 KB of LDS: 4 workgroups per CU, 4 waves per SIMD -- the queue work is latency-bound and
+// needs the other waves to fill its gaps.
 
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -83,7 +88,7 @@ __device__ __forceinline__ void mf_split(float v, _Float16& hi, _Float16& lo)
 }
 
 // Per-model constants of the MFMA tier.  A model (or threshold) outside the tier's domain gets s = 1, d = 0: every
-// evaluation "survives" and is decided by the scalar tiers.  A slot past the end of the list gets d = 2^40: never survives.
+// evaluation "survives" and is decided by the scalar tiers.  A slot past the end of the list gets d = 2^15, s = 0: never survives.
 __device__ __forceinline__ void mf_model_setup(const double* F, bool live, float thr2, double Q1, double Q2, double P1, double P2,
                                                MfModel& o)
 {
@@ -208,7 +213,7 @@ __device__ __forceinline__ uint32_t mf_wave_scan(uint32_t x)
     return x;
 }
 
-// three VALU instructions per evaluation: sign(r) set <=> sure outlier
+// two VALU instructions per evaluation: sign(r) set <=> sure outlier
 __device__ __forceinline__ uint32_t mf_epilogue(const v16f& d, const v16f& s, uint32_t bits)
 {
 #pragma unroll
@@ -488,7 +493,7 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
             }
             uint32_t bits[2] = {0u, 0u};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {                   // tile q of the group: row block q >> 1, column block q & 1
+            for (int q = 0; q < 4; ++q) {                   // tile q of the group: correspondence block q >> 1, model block q & 1
                 const int h = q >> 1, cb = q & 1;
                 // second K step of d: lanes 0-31 pair phi hi with the lo coefficients, lanes 32-63 pair (1, 1, 0...) with c~_8
                 const uint4 adw = __builtin_bit_cast(uint4, ad[h]);       // (bit masks: a v_cndmask_b32 costs 12 cycles, a v_and_b32 2)
