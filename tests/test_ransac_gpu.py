@@ -121,6 +121,33 @@ def test_score_fund_fuzz(oracle_mod, dev, seed):
         assert np.array_equal(cnt, ref), (seed, thr, np.nonzero(cnt != ref)[0][:5])
 
 
+@pytest.mark.parametrize("n", [1000, 333, 64 * 5 + 1])
+def test_score_fund_many_models_walk_chunks(oracle_mod, dev, fund_models, n):
+    """The F count kernel's workgroups walk several chunks of 256 correspondences once there are enough model blocks
+    (csrc/vo_score_fmfma.h): 140 000 model rows (the fixture's models repeated) over point counts that leave a ragged
+    last chunk and a ragged last group of 64; every row's count equals the oracle's for its model."""
+    sc, p1, p2, models = fund_models
+    p1, p2 = p1[:n], p2[:n]
+    pts4 = np.concatenate([p1, p2], 1).astype(np.float32)
+    rows = 140_000
+    rep = models[np.arange(rows) % len(models)]
+    cnt = ops.score_fund(_d(rep, dev), _d(pts4, dev), 0.5).cpu().numpy()
+    ref = np.array([oracle_mod.find_inliers(oracle_mod.fund_error(m, p1, p2), 0.5)[0] for m in models])
+    assert np.array_equal(cnt, ref[np.arange(rows) % len(models)])
+
+
+def test_score_fund_every_evaluation_survives_the_first_tier(oracle_mod, dev, fund_models):
+    """A threshold as large as the image: (nearly) every evaluation passes the MFMA tier's sure-outlier test, so the
+    per-wave survivor queue overflows in every group and the lanes work their own survivor strings off."""
+    sc, p1, p2, models = fund_models
+    pts4 = np.concatenate([p1, p2], 1).astype(np.float32)
+    for thr in (400.0, 3000.0):
+        cnt = ops.score_fund(_d(models[:200], dev), _d(pts4, dev), thr).cpu().numpy()
+        ref = np.array([oracle_mod.find_inliers(oracle_mod.fund_error(m, p1, p2), thr)[0] for m in models[:200]])
+        assert np.array_equal(cnt, ref)
+        assert ref.mean() > 0.5 * len(p1)
+
+
 def test_score_valid_flags_and_empty(dev, fund_models):
     sc, p1, p2, models = fund_models
     pts4 = np.concatenate([p1, p2], 1).astype(np.float32)
