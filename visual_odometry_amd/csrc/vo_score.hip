@@ -242,7 +242,7 @@ __device__ __forceinline__ void fund_filter32_signs(const FundFilter32& f, float
     out_bits = __builtin_amdgcn_alignbit(out_bits, __float_as_uint(r_out), 31);
 }
 
-#if defined(VO_SCORE_STATS) || defined(VO_SCORE_MF_PROF)
+#if defined(VO_SCORE_STATS) || defined(VO_SCORE_MF_PROF) || defined(VO_SCORE_MF_CHECK)
 __device__ unsigned long long g_stats[8];
 extern "C" int vo_score_stats(unsigned long long* out8, int reset)
 {

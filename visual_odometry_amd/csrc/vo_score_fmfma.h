@@ -61,6 +61,9 @@ constexpr int kMfChunk = VO_SCORE_MF_CHUNK;
 constexpr int kMfEtaUnits = 48;
 
 struct MfModel {
+#ifdef VO_SCORE_MF_CHECK
+    double dbg_scale, dbg_unit;    // d~ = dbg_scale * d; one budget unit 2^-24 S~ (0 = model outside the tier's domain)
+#endif
     v8h ch, cl, c8, s0, s1;    // B operands: d coefficients hi / lo, (c~_8 hi, lo, 0...) against the A vector (1, 1, 0...);
                                // den2 entries for lane halves 0 / 1
 };
@@ -94,6 +97,9 @@ __device__ __forceinline__ void mf_model_setup(const double* F, bool live, float
 {
 #pragma unroll
     for (int k = 0; k < 8; ++k) { o.ch[k] = 0; o.cl[k] = 0; o.c8[k] = 0; o.s0[k] = 0; o.s1[k] = 0; }
+#ifdef VO_SCORE_MF_CHECK
+    o.dbg_scale = 0.; o.dbg_unit = 0.;
+#endif
     if (!live) { o.c8[0] = (_Float16)32768.f; return; }       // d = 2^15, s = 0: r = -2^30
     double fm = 0., nanprobe = 0.;
 #pragma unroll
@@ -164,6 +170,9 @@ __device__ __forceinline__ void mf_model_setup(const double* F, bool live, float
         o.c8[0] = hi; o.c8[1] = lo;
     }
     const double eta = ((double)kMfEtaUnits * 0x1p-24 * S + 0x1p-20) * up;
+#ifdef VO_SCORE_MF_CHECK
+    o.dbg_scale = sigma * kap; o.dbg_unit = 0x1p-24 * S;
+#endif
     _Float16 gh[5], gl[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) mf_split(G[k] * kap2, gh[k], gl[k]);
@@ -234,6 +243,9 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
     __shared__ uint4 planebuf[4 * C];                       // A operands: d hi, d lo, den2 half 0, den2 half 1 (C x 16 B each);
     uint4 (*planes)[C] = (uint4 (*)[C])planebuf;            // first the models' B operands pass through it (4 x 16 B each)
     uint4* const stagebuf = planebuf;
+#ifdef VO_SCORE_MF_CHECK
+    __shared__ double wdbg[kWaves][64][2];
+#endif
     __shared__ uint32_t wc8[kWaves][64];                    // (c~_8 hi, lo) of every model
     __shared__ float4 spf[C];                               // the chunk's correspondences, for the scalar tiers
     __shared__ double sscale[3][kWaves];
@@ -334,6 +346,9 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
             st[2] = __builtin_bit_cast(uint4, mm.s0);
             st[3] = __builtin_bit_cast(uint4, mm.s1);
             wc8[w][lane] = __builtin_bit_cast(uint4, mm.c8).x;
+#ifdef VO_SCORE_MF_CHECK
+            wdbg[w][lane][0] = mm.dbg_scale; wdbg[w][lane][1] = mm.dbg_unit;
+#endif
         }
         tlo = f32.tlo; thi = f32.thi;
     }
@@ -503,6 +518,25 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
                 v16f accd = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bd0[cb], ad[h], zero16, 0, 0, 0);
                 accd = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bd1[cb], a1, accd, 0, 0, 0);
                 const v16f accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bs[cb], as[h], zero16, 0, 0, 0);
+#ifdef VO_SCORE_MF_CHECK
+                // measurement build: the MFMA's d~ against the f64 value of kappa x2^T F x1, in budget units (eta = 48 of them)
+                for (int r = 0; r < 16; ++r) {
+                    const int m = 32 * cb + 8 * (r >> 2) + 4 * kh + (r & 3), pt = i0 + 32 * h + col;
+                    const double unit = wdbg[w][m][1];
+                    if (pt < np && unit > 0.) {
+                        const double* F = a.models + (size_t)wslot[w][m] * 9;
+                        const float4 v = spf[pt];
+                        const double x1 = v.x, y1 = v.y, x2 = v.z, y2 = v.w;
+                        const double aa = __builtin_fma(F[0], x1, __builtin_fma(F[1], y1, F[2])), bb = __builtin_fma(F[3], x1, __builtin_fma(F[4], y1, F[5])),
+                                     cc = __builtin_fma(F[6], x1, __builtin_fma(F[7], y1, F[8]));
+                        const double dd = __builtin_fma(x2, aa, __builtin_fma(y2, bb, cc)) * wdbg[w][m][0];
+                        const double units = fabs((double)accd[r] - dd) / unit;
+                        atomicMax(&g_stats[0], (unsigned long long)(units * 1000.));
+                        atomicAdd(&g_stats[1], 1ull);
+                        if (units > 4.) atomicAdd(&g_stats[2], 1ull);
+                    }
+                }
+#endif
 #if VO_SCORE_MF_ABLATE == 3
                 bits[h] |= ~(__float_as_uint(accd[0]) & __float_as_uint(accs[5]) & 1u);   // timing experiment: MFMAs without their epilogue
 #else
