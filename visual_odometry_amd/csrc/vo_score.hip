@@ -901,7 +901,7 @@ void score_kernel(const ScoreArgs a)
 #define VO_SCORE_F_MFMA 1             // 1: the F count kernel runs its first tier on the matrix cores (vo_score_fmfma.h)
 #endif
 #ifndef VO_SCORE_MF_TARGET
-#define VO_SCORE_MF_TARGET 1024       // workgroups wanted before a workgroup of the MFMA kernel walks more than one chunk
+#define VO_SCORE_MF_TARGET 4096       // workgroups wanted (4 rounds of the 1024 resident ones) before one walks several chunks; cfg5: 1024 -> 4096 = 2.40 -> 1.74 ms
 #endif
 #include "vo_score_fmfma.h"
 
