@@ -136,6 +136,17 @@ def test_score_fund_many_models_walk_chunks(oracle_mod, dev, fund_models, n):
     assert np.array_equal(cnt, ref[np.arange(rows) % len(models)])
 
 
+@pytest.mark.parametrize("n", [1, 7, 40, 64, 65, 255, 256, 257])
+def test_score_fund_few_correspondences(oracle_mod, dev, fund_models, n):
+    """Point counts around the group (64) and chunk (256) sizes of the MFMA tier, down to a single correspondence."""
+    sc, p1, p2, models = fund_models
+    p1, p2 = p1[:n], p2[:n]
+    pts4 = np.concatenate([p1, p2], 1).astype(np.float32)
+    cnt = ops.score_fund(_d(models, dev), _d(pts4, dev), 1.0).cpu().numpy()
+    ref = np.array([oracle_mod.find_inliers(oracle_mod.fund_error(m, p1, p2), 1.0)[0] for m in models])
+    assert np.array_equal(cnt, ref)
+
+
 def test_score_fund_every_evaluation_survives_the_first_tier(oracle_mod, dev, fund_models):
     """A threshold as large as the image: (nearly) every evaluation passes the MFMA tier's sure-outlier test, so the
     per-wave survivor queue overflows in every group and the lanes work their own survivor strings off."""
