@@ -38,7 +38,10 @@ int vo_launch_init_counts(const uint8_t* valid, const int32_t* nmodels, int slot
                           int32_t* counts, hipStream_t s);
 int vo_launch_score(int kind, const double* models, const uint8_t* valid, const int32_t* list, const int32_t* nstart,
                     const int32_t* nlist, int H, const void* pts, const float* img, const int32_t* n_dev, int N, int batch,
-                    const double* K4, float thr2, int32_t* counts, int max_slots, hipStream_t s);
+                    const double* K4, float thr2, int32_t* counts, int max_slots, hipStream_t s,
+                    const float* fund_bounds = nullptr);
+// per-problem bounds the F count kernel sets its models up with: (max |x1|,|y1|,1; max |x2|,|y2|,1; all coordinates tame ? 1 : 0; -)
+int vo_launch_fund_bounds(const void* pts, const int32_t* n_dev, int N, int batch, float* bounds, hipStream_t s);
 int vo_launch_mask_best(int kind, const double* models, int slots_per_problem, int slots_per_sample,
                         const double* aux, int aux_w, double* best_aux, const int32_t* result, const void* pts,
                         const float* img, const int32_t* n_dev, int N, int batch, const double* K4, float thr2,

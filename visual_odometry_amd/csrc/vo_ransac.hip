@@ -204,6 +204,7 @@ int vo_launch_replay(const int32_t* counts, const int32_t* nmodels, int n_iters,
 namespace {
 struct RansacWs {
     double* models; double* aux; int32_t* nmodels; int32_t* counts; int32_t* list; int32_t* nlist; int32_t* nstart;
+    float* bounds;                           // batch x 4: the F count kernel's per-problem coordinate bounds
     size_t zero_from, zero_bytes, bytes;     // [zero_from, zero_from + zero_bytes) is cleared per call
 };
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -217,6 +218,7 @@ RansacWs carve(void* base, int width, int mw, int aux_w, int H, int batch)
     w.aux = (double*)(p + off); off += align_up(slots * aux_w * sizeof(double));
     w.list = (int32_t*)(p + off); off += align_up(slots * sizeof(int32_t));
     w.nstart = (int32_t*)(p + off); off += align_up((size_t)batch * sizeof(int32_t));
+    w.bounds = (float*)(p + off); off += align_up((size_t)batch * 4 * sizeof(float));
     w.zero_from = off;
     w.nmodels = (int32_t*)(p + off); off += align_up((size_t)batch * H * sizeof(int32_t));
     w.counts = (int32_t*)(p + off); off += align_up(slots * sizeof(int32_t));
@@ -258,6 +260,10 @@ extern "C" int vo_ransac_batch(int kind, const int32_t* samples, int H, const vo
     // nmodels = 0 (iterations never solved hold no model), counts = 0, nlist = 0
     VO_HIP_TRY(hipMemsetAsync((char*)workspace + w.zero_from, 0, w.zero_bytes, s));
     const int Htot = H * batch;
+    if (kind == VO_KIND_FUND) {
+        const int rcb = vo_launch_fund_bounds(pts, n_dev, N, batch, w.bounds, s);
+        if (rcb != VO_OK) return rcb;
+    }
     // iteration blocks: [0, first_block), then blocks 4x as long as everything before, up to H.  After
     // each block the replay tells which problems OpenCV's loop would already have left (niters <= block
     // end); their later blocks cost nothing but the launch.
@@ -284,7 +290,7 @@ extern "C" int vo_ransac_batch(int kind, const int32_t* samples, int H, const vo
         if (rc != VO_OK) return rc;
         vo_prof_begin(VO_STAGE_SCORE, kind | (stage << 8), s);
         rc = vo_launch_score(kind, w.models, nullptr, w.list, stage == 0 ? nullptr : w.nstart, w.nlist, H * width, pts, img,
-                             n_dev, N, batch, K4_host, thr2, w.counts, hlen * width, s);
+                             n_dev, N, batch, K4_host, thr2, w.counts, hlen * width, s, kind == VO_KIND_FUND ? w.bounds : nullptr);
         vo_prof_end(VO_STAGE_SCORE, s);
         if (rc != VO_OK) return rc;
         vo_prof_begin(VO_STAGE_REPLAY, kind | (stage << 8), s);

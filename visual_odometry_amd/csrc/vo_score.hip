@@ -469,6 +469,7 @@ struct ScoreArgs {
     const void* pts;          // F: batch x N float4; E: batch x N x 4 f64; PnP: batch x N x 3 f32
     const float2* img;        // PnP only: batch x N
     const int32_t* n_dev;     // per-problem correspondence count (<= N), may be null
+    const float* bounds;      // F, MFMA kernel: batch x 4 precomputed coordinate bounds (vo_launch_fund_bounds), may be null
     int32_t* counts;          // batch x H
     int H, N, chunk;
     float thr2;
@@ -1187,15 +1188,57 @@ int vo_launch_init_counts(const uint8_t* valid, const int32_t* nmodels, int slot
     return VO_OK;
 }
 
+namespace {
+// one workgroup per problem: what every workgroup of score_fund_mfma_kernel would otherwise find for itself
+__global__ __launch_bounds__(256)
+void fund_bounds_kernel(const float4* __restrict__ pts, const int32_t* __restrict__ n_dev, int N, float* __restrict__ bounds)
+{
+    __shared__ float sq[3][4];
+    const int b = blockIdx.x, n = n_dev ? min(n_dev[b], N) : N;
+    pts += (size_t)b * N;
+    float q1 = 1.f, q2 = 1.f;
+    bool tame = true;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float4 v = pts[i];
+        q1 = fmaxf(q1, fmaxf(fabsf(v.x), fabsf(v.y)));
+        q2 = fmaxf(q2, fmaxf(fabsf(v.z), fabsf(v.w)));
+        tame = tame && fabsf(v.x) <= 0x1p20f && fabsf(v.y) <= 0x1p20f && fabsf(v.z) <= 0x1p20f && fabsf(v.w) <= 0x1p20f;
+    }
+    for (int o = 32; o; o >>= 1) {
+        q1 = fmaxf(q1, __shfl_xor(q1, o));
+        q2 = fmaxf(q2, __shfl_xor(q2, o));
+    }
+    tame = __all(tame);
+    if ((threadIdx.x & 63) == 0) { sq[0][threadIdx.x >> 6] = q1; sq[1][threadIdx.x >> 6] = q2; sq[2][threadIdx.x >> 6] = tame ? 1.f : 0.f; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float4 o;
+        o.x = fmaxf(fmaxf(sq[0][0], sq[0][1]), fmaxf(sq[0][2], sq[0][3]));
+        o.y = fmaxf(fmaxf(sq[1][0], sq[1][1]), fmaxf(sq[1][2], sq[1][3]));
+        o.z = fminf(fminf(sq[2][0], sq[2][1]), fminf(sq[2][2], sq[2][3]));
+        o.w = 0.f;
+        *(float4*)(bounds + 4 * (size_t)b) = o;
+    }
+}
+}  // namespace
+
+int vo_launch_fund_bounds(const void* pts, const int32_t* n_dev, int N, int batch, float* bounds, hipStream_t s)
+{
+    if (batch == 0 || N == 0) return VO_OK;
+    hipLaunchKernelGGL(fund_bounds_kernel, dim3(batch), dim3(256), 0, s, (const float4*)pts, n_dev, N, bounds);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}
+
 int vo_launch_score(int kind, const double* models, const uint8_t* valid, const int32_t* list, const int32_t* nstart,
                     const int32_t* nlist, int H, const void* pts, const float* img, const int32_t* n_dev, int N, int batch,
-                    const double* K4, float thr2, int32_t* counts, int max_slots, hipStream_t s)
+                    const double* K4, float thr2, int32_t* counts, int max_slots, hipStream_t s, const float* fund_bounds)
 {
     // H = model slots per problem (array stride); max_slots <= H bounds how many this launch can score
     if (H == 0 || N == 0 || batch == 0) return VO_OK;
     ScoreArgs a;
     a.models = models; a.valid = valid; a.list = list; a.nstart = nstart; a.nlist = nlist; a.pts = pts; a.img = (const float2*)img;
-    a.n_dev = n_dev; a.counts = counts; a.H = H; a.N = N; a.thr2 = thr2;
+    a.n_dev = n_dev; a.counts = counts; a.H = H; a.N = N; a.thr2 = thr2; a.bounds = fund_bounds;
     if (max_slots <= 0 || max_slots > H) max_slots = H;
     if (kind == kFund && VO_SCORE_F_MFMA) {
         // chunks of 512 correspondences; a workgroup walks every gy-th chunk with its models' operands in registers

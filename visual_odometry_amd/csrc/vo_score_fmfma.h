@@ -289,7 +289,10 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
 
     // problem-wide bounds on max(|x|,|y|,1) of either image (the models' constants are set up once for all chunks);
     // f32 maxima of f32 values are exact, four loads in flight per thread
-    {
+    if (a.bounds) {                                          // block-uniform: found once per problem by vo_launch_fund_bounds
+        const float4 pb = *(const float4*)(a.bounds + 4 * (size_t)b);
+        if (lane == 0) { sscale[0][w] = (double)pb.x; sscale[1][w] = (double)pb.y; sscale[2][w] = (double)pb.z; }
+    } else {
         float q1 = 1.f, q2 = 1.f;
         bool tame = true;
         for (int i = threadIdx.x; i < n; i += 4 * kThreads) {
