@@ -1,6 +1,8 @@
 #!/bin/bash
 # Builds whole-library variants of the F count kernel for same-box A/B runs (scripts/gpu_ab_libs.sh "ablate/libvo_mf_*.so"):
 #   usage: mf_variants.sh name:"-DFLAG=..." [name:"flags" ...]      -> ablate/libvo_mf_<name>.so
+# The VO_SCORE_MF_ABLATE=1..4 timing branches (wrong counts) are not in the shipped header: apply
+# scripts/experiments/mf_ablation_branches.patch (patch -p1) to a working copy first and revert afterwards.
 cd "$(dirname "$0")/../visual_odometry_amd/csrc" || exit 1
 mkdir -p ../../ablate/objs
 OTHERS=$(ls _obj/*.o | grep -v vo_score.o)

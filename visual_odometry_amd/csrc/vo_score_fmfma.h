@@ -41,9 +41,6 @@
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-#ifndef VO_SCORE_MF_ABLATE
-#define VO_SCORE_MF_ABLATE 0            // timing experiments only (scripts/mf_variants.sh); anything but 0 gives wrong counts
-#endif
 #ifdef VO_SCORE_MF_PROF                  // wave-time per phase (s_memtime ticks) into g_stats[0..5]: scripts/diag/mf_phases.py
 #define MF_T(var) const long long var = __builtin_amdgcn_s_memtime()
 #define MF_ACC(slot, t0, t1) prof[slot] += (t1) - (t0)
@@ -497,9 +494,6 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
         asm volatile("" : "+v"(keep), "+v"(ones));
         uint32_t q1 = 0;                                     // wave-uniform: entries waiting in the tier-1b queue
         const v16f zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#if VO_SCORE_MF_ABLATE == 2
-        if (gy != 12345) continue;                           // timing experiment: set-up and staging only
-#endif
         for (int g = 0; g < ngroups; ++g) {
             const int i0 = 64 * g;
             MF_T(ta0);
@@ -540,17 +534,10 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
                     }
                 }
 #endif
-#if VO_SCORE_MF_ABLATE == 3
-                bits[h] |= ~(__float_as_uint(accd[0]) & __float_as_uint(accs[5]) & 1u);   // timing experiment: MFMAs without their epilogue
-#else
                 bits[h] = mf_epilogue(accd, accs, bits[h]);
-#endif
             }
             // bit 32 (1 - h) + 31 - n: correspondence i0 + 32 h + column, model 32 cb + row of accumulator r, n = 16 cb + r
             unsigned long long cand = ~(((unsigned long long)bits[0] << 32) | bits[1]);
-#if VO_SCORE_MF_ABLATE == 1
-            if (cand != 0x123456789ull) cand = 0;            // timing experiment: tier 1a only (wrong counts)
-#endif
             if (i0 + 64 > np)                                // ragged end of the chunk: padding points decide nothing
                 cand &= (i0 + col < np ? 0xffffffff00000000ull : 0ull) | (i0 + 32 + col < np ? 0xffffffffull : 0ull);
             MF_T(ta1);
@@ -577,9 +564,6 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
                 }
                 q1 = q1new;
                 wave_sync();
-#if VO_SCORE_MF_ABLATE == 4
-                if (gy != 12345) q1 = 0;                     // timing experiment: survivors are queued, then dropped
-#endif
                 MF_T(tb1);
                 MF_ACC(2, ta1, tb1);
                 if (q1 >= (uint32_t)kBatch) {
