@@ -385,16 +385,22 @@ def worker(args) -> int:
     # shard mode: this rank scores its slice of every F problem's iterations and whole PnP problems of its pairs
     h_f = parallel.shard_bounds(HF, rank, world) if shard else (0, HF)
     p_pairs = range(*parallel.shard_bounds(B, rank, world)) if shard else range(B)
-    nm_f, nm_p = [], []
-    for b in range(B):
-        n = int(n_match[b])
-        if ess:
-            nm_f.append(ops.solve_5pt(res.e_samples[b], res.pts4n[b, :n])[1].cpu().numpy())
-        else:
-            nm_f.append(ops.solve_7pt(res.f_samples[b, h_f[0]:h_f[1]], res.pts4[b, :n])[1].cpu().numpy())
-    for b in (p_pairs if HP > 0 else []):
-        n = int(n_match[b])
-        nm_p.append(ops.solve_p3p(res.p_samples[b], res.obj[b, :n], res.img[b, :n], ps.K)[2].cpu().numpy())
+    # one solver launch per chain over all pairs (pair b's sample indices shifted into the flattened point array), so
+    # that the kernel trace of a bench run holds no per-pair accounting launches
+    def count_models(solve, samples, *arrays):
+        nb, hh, m = samples.shape
+        stride = arrays[0].shape[1]
+        shift = (torch.arange(nb, device=samples.device, dtype=torch.int32) * stride).view(nb, 1, 1)
+        out = solve((samples + shift).reshape(nb * hh, m), *[a.reshape(nb * stride, -1) for a in arrays])
+        return list(out[-1].reshape(nb, hh).cpu().numpy())
+    if ess:
+        nm_f = count_models(ops.solve_5pt, res.e_samples, res.pts4n)
+    else:
+        nm_f = count_models(ops.solve_7pt, res.f_samples[:, h_f[0]:h_f[1]], res.pts4)
+    nm_p = []
+    if HP > 0:
+        sel = torch.tensor(list(p_pairs), dtype=torch.long, device=dev)
+        nm_p = count_models(lambda sm, o, i: ops.solve_p3p(sm, o, i, ps.K), res.p_samples[sel], res.obj[sel], res.img[sel])
     mf = [int(x.sum()) for x in nm_f] if shard else models_scored(nm_f, res_f, HF, FIRST_BLOCK if ess else 0)
     mp = models_scored(nm_p, res_p[list(p_pairs)], HP, FIRST_BLOCK) if HP > 0 else []
     evals_f = int(sum(m * n for m, n in zip(mf, n_match)))
