@@ -121,6 +121,42 @@ def test_score_fund_fuzz(oracle_mod, dev, seed):
         assert np.array_equal(cnt, ref), (seed, thr, np.nonzero(cnt != ref)[0][:5])
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_score_fund_mixed_dynamic_range_and_unbalanced_models(oracle_mod, dev, seed):
+    """What the scene fuzz does not produce (scripts/diag/fscore_fuzz_adversarial.py ran 200 seeds of it): a few far points set
+    the problem-wide power-of-two scaling (bound up to 2^19) and everything else is tiny against it, so the f16 lo halves of
+    the matrix-core tier's split coordinates go subnormal or vanish; points at the origin; models with entries of unbalanced
+    magnitude, sparse and rank-one models; thresholds from 1e-3 to 1e2 of the image scale.  Counts equal the oracle's."""
+    rng = np.random.default_rng(900 + seed)
+    n = int(rng.integers(40, 1500))
+    W = float(10 ** rng.uniform(-1, 3))
+    sc = synth.two_view_scene(n, seed=900 + seed, outlier_frac=float(rng.uniform(0, 0.5)), noise_px=float(rng.uniform(0, 1)))
+    p1 = sc["p1"] * (W / 1024.0); p2 = sc["p2"] * (W / 1024.0)
+    subs = oracle_mod.gen_subsets(n, 7, 30, p1.astype(np.float32), p2.astype(np.float32))
+    models = [F.reshape(9) for s_ in subs for F in oracle_mod.run7point(p1[s_].astype(np.float32), p2[s_].astype(np.float32))]
+    if seed % 4:
+        far = rng.choice(n, size=max(1, n // 50), replace=False)
+        big = 2.0 ** rng.uniform(4, 19 - np.log2(max(W, 1.0)), size=(len(far), 1))
+        if seed % 4 in (1, 3): p1[far] = p1[far] * big
+        if seed % 4 in (2, 3): p2[far] = p2[far] * big
+    if seed % 4 == 2:
+        z = rng.choice(n, size=5, replace=False)
+        p1[z[:3]] = 0.0; p2[z[2:]] = rng.uniform(-1e-6, 1e-6, (3, 2)) * W
+    p1 = p1.astype(np.float32); p2 = p2.astype(np.float32)
+    for _ in range(30):
+        models.append((rng.standard_normal((3, 3)) * 10 ** rng.uniform(-3, 3, (3, 3))).reshape(9))
+    for _ in range(8):
+        models.append((rng.standard_normal((3, 3)) * (rng.uniform(0, 1, (3, 3)) < 0.5)).reshape(9))
+    for _ in range(8):
+        models.append(np.outer(rng.standard_normal(3), rng.standard_normal(3)).reshape(9))
+    models = np.array(models, dtype=np.float64)
+    pts4 = np.concatenate([p1, p2], 1).astype(np.float32)
+    for thr in 10 ** rng.uniform(-3, 2, 3) * W:
+        cnt = ops.score_fund(_d(models, dev), _d(pts4, dev), float(thr)).cpu().numpy()
+        ref = np.array([oracle_mod.find_inliers(oracle_mod.fund_error(m, p1, p2), float(thr))[0] for m in models])
+        assert np.array_equal(cnt, ref), (seed, thr, W, np.nonzero(cnt != ref)[0][:5])
+
+
 @pytest.mark.parametrize("n", [1000, 333, 64 * 5 + 1])
 def test_score_fund_many_models_walk_chunks(oracle_mod, dev, fund_models, n):
     """The F count kernel's workgroups walk several chunks of 256 correspondences once there are enough model blocks
