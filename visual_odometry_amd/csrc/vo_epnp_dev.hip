@@ -2,7 +2,7 @@
 // SURVEY.md Appendix A.5) for a batch of frame pairs on the device: the pose OpenCV returns is EPnP over
 // the inliers of the winning P3P model, so the batched pipeline needs it next to the RANSAC results.
 //
-// One 256-thread workgroup per pair.  Everything that is O(inliers) -- centroid, covariance, the 12x12
+// One 128-thread workgroup per pair (VO_EPNP_THREADS).  Everything that is O(inliers) -- centroid, covariance, the 12x12
 // normal matrix M^T M, the cross-covariance of the absolute orientation, the mean reprojection error
 // -- is a block reduction in a fixed tree order (deterministic run to run); the small dense algebra
 // in between (3x3 / 12x12 Jacobi SVD, the 6x10 system of the betas, Gauss-Newton) is the code of the
@@ -15,7 +15,10 @@ namespace {
 
 using namespace vo_epnp;
 
-constexpr int kThreads = 256;
+#ifndef VO_EPNP_THREADS
+#define VO_EPNP_THREADS 128             // 2 waves: the kernel is latency-bound and shares its CU with the F chain
+#endif
+constexpr int kThreads = VO_EPNP_THREADS;
 constexpr int kWaves = kThreads / 64;
 
 // sum of v[k] over the workgroup, result in every thread; sh holds kWaves * K doubles

@@ -370,10 +370,11 @@ void knn2_merge_kernel(const int4* __restrict__ partial, const int32_t* __restri
     *(int2*)(d2 + o) = make_int2(r.j1 >= 0 ? qn - r.k1 : INT_MAX, r.j2 >= 0 ? qn - r.k2 : INT_MAX);
 }
 
-// f32 (integers 0..255) -> int8 (value-128) + squared norm of the int8 row; 32 lanes per row, four rows
+// f32 (integers 0..255) -> int8 (value-128) + squared norm of the int8 row; 32 lanes per row, eight rows
 // per lane group with their loads issued together (the kernel is a pure HBM stream: 512 B in, 132 B out
-// per row, and one 16-byte load per thread in flight does not cover the latency)
-constexpr int kDescRowsPerGroup = 4;
+// per row, and one 16-byte load per thread in flight does not cover the latency); the loads are
+// non-temporal -- every byte is read once.  Standalone, 2 M rows: 220 us = 6.1 TB/s (4 rows, plain loads: 233)
+constexpr int kDescRowsPerGroup = 8;
 __global__ __launch_bounds__(256)
 void desc_f32_to_i8_kernel(const float* __restrict__ desc, int n, int8_t* __restrict__ out,
                            int32_t* __restrict__ norm, int32_t* __restrict__ flags)
@@ -383,7 +384,11 @@ void desc_f32_to_i8_kernel(const float* __restrict__ desc, int n, int8_t* __rest
 #pragma unroll
     for (int r = 0; r < kDescRowsPerGroup; ++r) {
         const int row = row0 + r < n ? row0 + r : n - 1;
-        v[r] = *(const float4*)(desc + (size_t)row * kDim + 4 * l);
+        {
+            typedef float vf4 __attribute__((ext_vector_type(4)));
+            const vf4 t = __builtin_nontemporal_load((const vf4*)(desc + (size_t)row * kDim + 4 * l));
+            v[r] = make_float4(t.x, t.y, t.z, t.w);
+        }
     }
     int bad = 0;
 #pragma unroll
@@ -417,7 +422,9 @@ void desc_f32_to_i8_kernel(const float* __restrict__ desc, int n, int8_t* __rest
             if (su > (1 << 20)) bad |= VO_DESC_BAD_NORM;
         }
     }
-    if (bad) atomicOr(flags, bad);
+    // (a launch full of bad rows would otherwise serialise on this one word at ~10 ns per atomic: once the bits are set,
+    // later lanes see them and skip the atomic; OR is idempotent, so the race is harmless)
+    if (bad && (__atomic_load_n(flags, __ATOMIC_RELAXED) & bad) != bad) atomicOr(flags, bad);
 }
 
 // grid-stride, one atomic per workgroup: a counter bumped once per wave serialises the whole launch
