@@ -61,7 +61,7 @@ struct MfModel {
 #ifdef VO_SCORE_MF_CHECK
     double dbg_scale, dbg_unit;    // d~ = dbg_scale * d; one budget unit 2^-24 S~ (0 = model outside the tier's domain)
 #endif
-    v8h ch, cl, c8, s0, s1;    // B operands: d coefficients hi / lo, (c~_8 hi, lo, 0...) against the A vector (1, 1, 0...);
+    v8h ch, cl, c8, s0, s1;    // model-side operands: d coefficients hi / lo, (c~_8 hi, lo, 0...) against the point-side vector (1, 1, 0...);
                                // den2 entries for lane halves 0 / 1
 };
 
@@ -181,7 +181,7 @@ __device__ __forceinline__ void mf_model_setup(const double* F, bool live, float
     o.s1 = v8h{gh[3], gh[4], gl[0], gl[1], gl[2], gl[3], gl[4], g1h};
 }
 
-// Split features of one correspondence into the four A-operand planes.  (x1 y1 x2 y2) arrive scaled by exact powers of
+// Split features of one correspondence into the four point-side operand planes.  (x1 y1 x2 y2) arrive scaled by exact powers of
 // two to [-1, 1]; a padding point (real = false, v = 0) gets all-zero features, the constant 1 of den2 included.
 __device__ __forceinline__ void mf_stage_point(float4 v, bool real, float iP1, float iP2, uint4& dh, uint4& dl, uint4& s0, uint4& s1)
 {
@@ -237,8 +237,8 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
     constexpr int kNE = VO_SCORE_NE, kBatch = 64 * kNE;
     constexpr int kListCap = 256, kQueueCap = 64 + kBatch;
     static_assert(C >= kThreads, "the models' operands are staged through the feature planes");
-    __shared__ uint4 planebuf[4 * C];                       // A operands: d hi, d lo, den2 half 0, den2 half 1 (C x 16 B each);
-    uint4 (*planes)[C] = (uint4 (*)[C])planebuf;            // first the models' B operands pass through it (4 x 16 B each)
+    __shared__ uint4 planebuf[4 * C];                       // the correspondences' operands: d hi, d lo, den2 half 0, den2 half 1 (C x 16 B each);
+    uint4 (*planes)[C] = (uint4 (*)[C])planebuf;            // first the models' operands pass through it (4 x 16 B each)
     uint4* const stagebuf = planebuf;
 #ifdef VO_SCORE_MF_CHECK
     __shared__ double wdbg[kWaves][64][2];
@@ -326,7 +326,7 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
     const float iP1 = (float)ldexp(1., -e1), iP2 = (float)ldexp(1., -e2);
 
     // per-model constants: the scalar tiers' f32 filter (LDS, read by whichever lane works a queued pair) and the MFMA
-    // tier's B operands (staged through the feature planes, which nothing has written yet)
+    // tier's model-side operands (staged through the feature planes, which nothing has written yet)
     float tlo, thi;                                         // functions of the threshold alone
     {
         FundFilter32 f32;
@@ -355,6 +355,8 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
     __syncthreads();
     // (a wave past the end of the model list stays: it helps staging the chunks and keeps the barriers; its models are
     // "never survive" columns)
+    // (names from before the tile was transposed: Bd0 / Bd1 / Bs hold the MODELS' vectors and are the MFMA's first, row-side
+    // operand; ad / as below are the correspondences' and its second, column-side one)
     v8h Bd0[2], Bd1[2], Bs[2];
     if (fast) {
 #pragma unroll
