@@ -51,6 +51,9 @@ RATIO = 0.8                   # reference src/params.py:10
 F_THR, F_CONF = 0.1, 0.9999   # reference src/params.py:24-27
 P_THR, P_CONF = 1.0, 0.9999   # reference src/params.py:72-75
 FIRST_BLOCK = 64              # PnP iterations evaluated before the first early-termination check (then x5 per block)
+# F iterations counted exactly before the first replay; the blocks behind it (x16 per block) count only the hypotheses
+# whose upper bound beats the best count so far (vo_ransac_batch; 0 = one block, every hypothesis counted exactly)
+F_FIRST_BLOCK = int(os.environ.get("VO_BENCH_F_FIRST_BLOCK", "256"))
 
 CONFIGS = {
     "cfg4": dict(nq=8192, nt=8192, f_iters=4096, p_iters=4096, pairs=256, landmark_outliers=0.0),
@@ -186,7 +189,8 @@ def step(ps: PairSet, cfg, group, prefetch: bool = False, pose_tail: bool = True
                                          first_block_e=FIRST_BLOCK)
     res = pipeline.match_and_ransac(ps.q, ps.t, ps.kp_q, ps.kp_t, RATIO, F_THR, F_CONF, cfg["f_iters"], xyz_q=ps.xyz_q,
                                     K=ps.K, p_threshold=P_THR, p_confidence=P_CONF, p_iters=cfg["p_iters"],
-                                    first_block_pnp=FIRST_BLOCK, workspace=ps.ws, wait_pnp=False, group=group, prepared=prepared)
+                                    first_block_pnp=FIRST_BLOCK, first_block_f=F_FIRST_BLOCK if group is None else 0,
+                                    workspace=ps.ws, wait_pnp=False, group=group, prepared=prepared)
     if pose_tail:
         # "R,t out" of the 2D-2D chain (reference src/twoDtwoD.py:57-79): E = K^T F K -> decomposeEssentialMatrix ->
         # disambiguateRelativePose over the F inliers, on the device, behind the F-RANSAC.  Weak mode: on a side stream
@@ -275,26 +279,26 @@ def cpu_baseline(cfg, max_seconds: float = 25.0, ess: bool = False):
                       f"OpenCV routines, not OpenCV"}
 
 
-def iteration_blocks(H, first):
+def iteration_blocks(H, first, grow=5):
     out, h0, stage = [], 0, 0
     while h0 < H:
         h1 = H
         if 0 < first < H:
-            h1 = first if stage == 0 else min(h0 * 5, H)
+            h1 = first if stage == 0 else min(h0 * grow, H)
         if H - h1 < h1 // 4:
             h1 = H
         out.append((h0, h1)); h0 = h1; stage += 1
     return out
 
 
-def models_scored(nm, result, H, first):
+def models_scored(nm, result, H, first, grow=5):
     """Models the scoring launches evaluated: samples without a solution have none, and iteration
     blocks that start where OpenCV's loop has already ended are skipped (block k ran iff
     h0_k <= best_iter or h0_k < final niters)."""
     per_pair = []
     for b in range(len(nm)):
         best_iter, niters = int(result[b, 0]), int(result[b, 3])
-        per_pair.append(sum(int(nm[b][h0:h1].sum()) for h0, h1 in iteration_blocks(H, first)
+        per_pair.append(sum(int(nm[b][h0:h1].sum()) for h0, h1 in iteration_blocks(H, first, grow)
                             if h0 == 0 or h0 <= best_iter or h0 < niters))
     return per_pair
 
@@ -401,7 +405,7 @@ def worker(args) -> int:
     if HP > 0:
         sel = torch.tensor(list(p_pairs), dtype=torch.long, device=dev)
         nm_p = count_models(lambda sm, o, i: ops.solve_p3p(sm, o, i, ps.K), res.p_samples[sel], res.obj[sel], res.img[sel])
-    mf = [int(x.sum()) for x in nm_f] if shard else models_scored(nm_f, res_f, HF, FIRST_BLOCK if ess else 0)
+    mf = [int(x.sum()) for x in nm_f] if shard else (models_scored(nm_f, res_f, HF, FIRST_BLOCK) if ess else models_scored(nm_f, res_f, HF, F_FIRST_BLOCK, grow=16))
     mp = models_scored(nm_p, res_p[list(p_pairs)], HP, FIRST_BLOCK) if HP > 0 else []
     evals_f = int(sum(m * n for m, n in zip(mf, n_match)))
     evals_p = int(sum(m * n for m, n in zip(mp, n_match[list(p_pairs)])))

@@ -97,6 +97,12 @@ int vo_ratio_test(const int32_t* d2, int n, double ratio, uint8_t* keep, int32_t
  * point-to-epipolar-line distance (FMEstimatorCallback::computeError, fundam.cpp). */
 int vo_score_fund(const double* models, const uint8_t* valid, int H,
                   const float* pts, int N, float thr2, int32_t* counts, void* stream);
+/* Upper bounds instead of counts: bound[h] >= the count vo_score_fund would give model h, from the first (matrix-core)
+ * tier of the F count kernel alone -- the correspondences it cannot prove to be outliers.  Inside cv2.findFundamentalMat's
+ * RANSAC loop (reference src/utils/geometry.py:21-23; RANSACPointSetRegistrator::run acts only on
+ * goodCount > maxGoodCount) a hypothesis whose bound does not exceed the best count so far needs no exact count:
+ * vo_ransac_batch uses this for the iteration blocks behind the first.  No `valid` array: every model is bounded. */
+int vo_score_fund_bound(const double* models, int H, const float* pts, int N, float thr2, int32_t* bound, void* stream);
 /* models H x 9 f64 (row-major E), pts N x 4 f64 (K-normalised x1 y1 x2 y2).  Sampson
  * error (EMEstimatorCallback::computeError, five-point.cpp). */
 int vo_score_ess(const double* models, const uint8_t* valid, int H,

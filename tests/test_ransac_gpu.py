@@ -157,6 +157,59 @@ def test_score_fund_mixed_dynamic_range_and_unbalanced_models(oracle_mod, dev, s
         assert np.array_equal(cnt, ref), (seed, thr, W, np.nonzero(cnt != ref)[0][:5])
 
 
+@pytest.mark.parametrize("thr", [0.1, 1.0, 5.0])
+def test_score_fund_bound_is_never_below_the_count(oracle_mod, dev, fund_models, thr):
+    """vo_score_fund_bound (the matrix-core tier alone, what vo_ransac_batch prunes hopeless hypotheses with): an upper bound
+    of every model's inlier count -- also for zero / NaN / absurdly scaled models and for a problem with non-finite
+    coordinates, where nothing can be proven and the bound is the number of correspondences -- and a tight one on scene data."""
+    sc, p1, p2, models = fund_models
+    pts4 = np.concatenate([p1, p2], 1).astype(np.float32)
+    odd = np.array([np.zeros(9), np.full(9, np.nan), models[0] * 1e300, models[1] * 1e-300, np.full(9, np.inf)])
+    allm = np.concatenate([models, odd])
+    for n in (len(p1), 777, 65, 1):
+        ub = ops.score_fund_bound(_d(allm, dev), _d(pts4[:n], dev), thr).cpu().numpy()
+        cnt = ops.score_fund(_d(allm, dev), _d(pts4[:n], dev), thr).cpu().numpy()
+        assert np.all(ub >= cnt) and np.all(ub <= n), (thr, n, np.nonzero(ub < cnt)[0][:5])
+        assert np.all(ub[len(models):len(models) + 2] == n) and ub[-1] == n     # zero / NaN / Inf model: nothing proven
+        if n == len(p1):
+            assert (ub[:len(models)] - cnt[:len(models)]).sum() <= 0.5 * cnt[:len(models)].sum() + 0.01 * n * len(models)   # (den2 alone + the f16 band: ~3 % above a good model's count)
+    bad = pts4.copy(); bad[5, 2] = np.inf
+    ub = ops.score_fund_bound(_d(models, dev), _d(bad, dev), thr).cpu().numpy()
+    assert np.all(ub == len(bad))
+
+
+@pytest.mark.parametrize("thr,first_block", [(0.1, 8), (0.1, 100), (1.0, 37), (3.0, 64), (30.0, 16)])
+def test_ransac_batch_fund_pruned_blocks_equal_one_block(dev, thr, first_block):
+    """Blocks behind the first count only the hypotheses whose upper bound beats the best count so far (csrc/vo_score.hip:
+    vo_launch_score_fund_pruned): result record, F and mask are those of the single exact block, bit for bit -- problems
+    of different sizes in one batch (n_dev), one with every correspondence repeated four times (ties), one with fewer than
+    15 correspondences, a threshold so wide that every model is a contender."""
+    B, H, N = 6, 1500, 2400
+    rng = np.random.default_rng(int(thr * 10) + first_block)
+    pts = np.zeros((B, N, 4), np.float32); nd = np.zeros(B, np.int32); subs = np.zeros((B, H, 7), np.int32)
+    for b in range(B):
+        n = [2400, 300, 1000, 15, 12, 2000][b]
+        sc = synth.two_view_scene(n, seed=500 + b, outlier_frac=float(rng.uniform(0.1, 0.6)), noise_px=float(rng.uniform(0.05, 1.0)))
+        p = np.concatenate([sc["p1"], sc["p2"]], 1).astype(np.float32)
+        if b == 2:
+            p = np.tile(p[:250], (4, 1))
+        pts[b, :n] = p; nd[b] = n
+        if n >= 15:
+            subs[b] = ops.gen_subsets(n, 7, H, p)
+    nd[4] = 0                                                   # (a problem without correspondences: no model)
+    outs = []
+    for fb in (0, first_block):
+        res, best, _, mask = ops.ransac_batch(ops.KIND_FUND, _d(subs, dev), _d(pts, dev), thr, 0.9999, H, n_dev=_d(nd, dev),
+                                              first_block=fb)
+        outs.append((res.cpu().numpy(), best.cpu().numpy(), mask.cpu().numpy()))
+    (r0, f0, m0), (r1, f1, m1) = outs
+    assert np.array_equal(r0, r1), (r0, r1)
+    for b in range(B):
+        if r0[b, 0] >= 0:
+            assert np.array_equal(f0[b], f1[b]) and np.array_equal(m0[b, :nd[b]], m1[b, :nd[b]]), b
+    assert r0[0, 2] > 7 and r0[0, 0] >= 0                       # (the runs did find models)
+
+
 @pytest.mark.parametrize("n", [1000, 333, 64 * 5 + 1])
 def test_score_fund_many_models_walk_chunks(oracle_mod, dev, fund_models, n):
     """The F count kernel's workgroups walk several chunks of 256 correspondences once there are enough model blocks

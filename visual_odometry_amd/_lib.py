@@ -37,6 +37,7 @@ _SIGNATURES = {
     "vo_knn2_l2_i8": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "vo_ratio_test": (_i, [_vp, _i, _d, _vp, _vp, _vp]),
     "vo_score_fund": (_i, [_vp, _vp, _i, _vp, _i, _f, _vp, _vp]),
+    "vo_score_fund_bound": (_i, [_vp, _i, _vp, _i, _f, _vp, _vp]),
     "vo_score_ess": (_i, [_vp, _vp, _i, _vp, _i, _f, _vp, _vp]),
     "vo_score_pnp": (_i, [_vp, _vp, _i, _vp, _vp, C.POINTER(_d), _i, _f, _vp, _vp]),
     "vo_mask_fund": (_i, [_vp, _vp, _i, _f, _vp, _vp]),

@@ -205,6 +205,7 @@ namespace {
 struct RansacWs {
     double* models; double* aux; int32_t* nmodels; int32_t* counts; int32_t* list; int32_t* nlist; int32_t* nstart;
     float* bounds;                           // batch x 4: the F count kernel's per-problem coordinate bounds
+    int32_t* clist; int32_t* ncl;            // F only: contender list of a pruned scoring stage (vo_launch_score_fund_pruned)
     size_t zero_from, zero_bytes, bytes;     // [zero_from, zero_from + zero_bytes) is cleared per call
 };
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -219,6 +220,11 @@ RansacWs carve(void* base, int width, int mw, int aux_w, int H, int batch)
     w.list = (int32_t*)(p + off); off += align_up(slots * sizeof(int32_t));
     w.nstart = (int32_t*)(p + off); off += align_up((size_t)batch * sizeof(int32_t));
     w.bounds = (float*)(p + off); off += align_up((size_t)batch * 4 * sizeof(float));
+    w.clist = w.ncl = nullptr;
+    if (width == 3) {                                    // F
+        w.clist = (int32_t*)(p + off); off += align_up(slots * sizeof(int32_t));
+        w.ncl = (int32_t*)(p + off); off += align_up((size_t)batch * sizeof(int32_t));
+    }
     w.zero_from = off;
     w.nmodels = (int32_t*)(p + off); off += align_up((size_t)batch * H * sizeof(int32_t));
     w.counts = (int32_t*)(p + off); off += align_up(slots * sizeof(int32_t));
@@ -266,11 +272,13 @@ extern "C" int vo_ransac_batch(int kind, const int32_t* samples, int H, const vo
     }
     // iteration blocks: [0, first_block), then blocks 4x as long as everything before, up to H.  After
     // each block the replay tells which problems OpenCV's loop would already have left (niters <= block
-    // end); their later blocks cost nothing but the launch.
+    // end); their later blocks cost nothing but the launch.  F: blocks 15x as long -- behind the first block only
+    // upper bounds are computed for most hypotheses (a third of the cost), and every block costs a replay.
     int h0 = 0;
     for (int stage = 0; h0 < H; ++stage) {
         int h1 = H;
-        if (first_block > 0 && first_block < H) h1 = stage == 0 ? first_block : (h0 * 5 < H ? h0 * 5 : H);
+        const long grow = kind == VO_KIND_FUND ? 16 : 5;
+        if (first_block > 0 && first_block < H) h1 = stage == 0 ? first_block : (int)((long)h0 * grow < H ? (long)h0 * grow : H);
         if (H - h1 < h1 / 4) h1 = H;                     // do not leave a sliver for a last stage
         const int hlen = h1 - h0;
         const int32_t* prev = stage == 0 ? nullptr : result;
@@ -289,8 +297,14 @@ extern "C" int vo_ransac_batch(int kind, const int32_t* samples, int H, const vo
         vo_prof_end(VO_STAGE_SOLVE, s);
         if (rc != VO_OK) return rc;
         vo_prof_begin(VO_STAGE_SCORE, kind | (stage << 8), s);
-        rc = vo_launch_score(kind, w.models, nullptr, w.list, stage == 0 ? nullptr : w.nstart, w.nlist, H * width, pts, img,
-                             n_dev, N, batch, K4_host, thr2, w.counts, hlen * width, s, kind == VO_KIND_FUND ? w.bounds : nullptr);
+        // F, blocks behind the first: the replay of the earlier blocks has left every problem's best count in `result`, and
+        // only a hypothesis that can beat it needs an exact count (vo_score.hip: upper bounds from the matrix-core tier)
+        if (kind == VO_KIND_FUND && stage > 0)
+            rc = vo_launch_score_fund_pruned(w.models, w.list, w.nstart, w.nlist, H * width, pts, n_dev, N, batch, thr2, w.counts,
+                                             hlen * width, w.bounds, result, w.clist, w.ncl, s);
+        else
+            rc = vo_launch_score(kind, w.models, nullptr, w.list, stage == 0 ? nullptr : w.nstart, w.nlist, H * width, pts, img,
+                                 n_dev, N, batch, K4_host, thr2, w.counts, hlen * width, s, kind == VO_KIND_FUND ? w.bounds : nullptr);
         vo_prof_end(VO_STAGE_SCORE, s);
         if (rc != VO_OK) return rc;
         vo_prof_begin(VO_STAGE_REPLAY, kind | (stage << 8), s);

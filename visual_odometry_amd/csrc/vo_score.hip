@@ -1266,6 +1266,101 @@ int vo_launch_score(int kind, const double* models, const uint8_t* valid, const 
     return VO_OK;
 }
 
+namespace {
+// Exact counts of the contenders of a pruned stage: they are few (tens per problem) and they are the GOOD hypotheses, dense
+// in survivors -- the opposite of what score_fund_mfma_kernel's queues are built for -- so each is simply walked by a whole
+// workgroup, thread per correspondence: the complete f32 filter, fund_decide64 where it cannot tell.  Workgroup j of
+// problem b takes contenders j, j + gridDim.x, ...
+__global__ __launch_bounds__(256)
+void count_contenders_kernel(const double* __restrict__ models, const int32_t* __restrict__ clist, const int32_t* __restrict__ ncl,
+                             int Hs, const float4* __restrict__ pts_all, const int32_t* __restrict__ n_dev, int N, float thr2,
+                             const float* __restrict__ bounds, int32_t* __restrict__ counts)
+{
+    const int b = blockIdx.y, nc = ncl[b];
+    if ((int)blockIdx.x >= nc) return;
+    const int n = n_dev ? min(n_dev[b], N) : N;
+    const float4* const pts = pts_all + (size_t)b * N;
+    const float4 pb = *(const float4*)(bounds + 4 * (size_t)b);
+    const double p1 = (double)pb.x, p2 = (double)pb.y;
+    __shared__ int und[4 * 256];
+    __shared__ int nund;
+    for (int c = blockIdx.x; c < nc; c += gridDim.x) {
+        const size_t gs = (size_t)b * Hs + clist[(size_t)b * Hs + c];
+        const double* const model = models + gs * 9;
+        double M[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) M[k] = model[k];
+        const FundFilter32 f32 = fund_filter32_setup(M, thr2, p1, p2);
+        int cnt = 0;
+        for (int i0 = 0; i0 < n; i0 += 4 * 256) {           // four loads in flight per thread
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256 + threadIdx.x;
+                v[u] = i < n ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (threadIdx.x == 0) nund = 0;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256 + threadIdx.x;
+                const int verdict = i < n ? fund_filter32(f32, v[u].x, v[u].y, v[u].z, v[u].w) : -1;
+                cnt += verdict > 0;
+                if (verdict == 0) und[atomicAdd(&nund, 1)] = i;
+            }
+            __syncthreads();
+            // what the f32 filter cannot tell (a good model has many residuals next to the threshold) is pooled over the
+            // workgroup, so that the f64 decisions run with full waves
+            const int nu = nund;
+            for (int t = threadIdx.x; t < nu; t += 256) {
+                const float4 w = pts[und[t]];
+                cnt += fund_decide64(model, w.x, w.y, w.z, w.w, thr2, p1, p2) ? 1 : 0;
+            }
+            __syncthreads();
+        }
+        for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(counts + gs, cnt);
+    }
+}
+}  // namespace
+
+// F scoring inside a RANSAC run whose earlier iterations have been replayed (result[4 b + 2] = best count so far of problem
+// b): the matrix-core tier alone gives every model of list entries [nstart, nlist) an upper bound of its count; only the
+// contenders -- bound above the best count -- are counted exactly.  counts[slot] ends as the exact count for contenders and
+// as an upper bound <= the best count for everybody else, which OpenCV's loop (good > maxGoodCount) cannot tell apart.
+// clist: batch x Hs ints, ncl: batch ints (scratch).
+int vo_launch_score_fund_pruned(const double* models, const int32_t* list, const int32_t* nstart, const int32_t* nlist, int Hs,
+                                const void* pts, const int32_t* n_dev, int N, int batch, float thr2, int32_t* counts,
+                                int max_slots, const float* fund_bounds, const int32_t* result, int32_t* clist, int32_t* ncl,
+                                hipStream_t s)
+{
+    if (Hs == 0 || N == 0 || batch == 0) return VO_OK;
+    VO_CHECK_ARG(batch <= 65535, VO_ESIZE, "score: batch=%d too large", batch);
+    VO_CHECK_ARG(fund_bounds != nullptr, VO_EINVAL, "score: the pruned F stage needs the per-problem coordinate bounds");
+    if (max_slots <= 0 || max_slots > Hs) max_slots = Hs;
+    ScoreArgs a;
+    a.models = models; a.valid = nullptr; a.list = list; a.nstart = nstart; a.nlist = nlist; a.pts = pts; a.img = nullptr;
+    a.n_dev = n_dev; a.counts = counts; a.H = Hs; a.N = N; a.thr2 = thr2; a.bounds = fund_bounds;
+    a.chunk = kMfChunk;
+    a.fx = a.fy = a.cx = a.cy = 0;
+    const int nchunks = vo_ceil_div(N, kMfChunk), xblocks = vo_ceil_div(max_slots, kThreads);
+    const long mblocks = (long)xblocks * batch;
+    long gy = (VO_SCORE_MF_TARGET + mblocks - 1) / mblocks;
+    if (gy > nchunks) gy = nchunks;
+    if (gy < 1) gy = 1;
+    VO_HIP_TRY(hipMemsetAsync(ncl, 0, (size_t)batch * sizeof(int32_t), s));
+    hipLaunchKernelGGL(screen_fund_mfma_kernel, dim3(xblocks, (unsigned)gy, batch), dim3(kThreads), 0, s, a, (int)gy);
+    VO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(screen_finalize_kernel, dim3(xblocks < 64 ? xblocks : 64, batch), dim3(256), 0, s, list, nstart, nlist, Hs,
+                       n_dev, N, result, counts, clist, ncl);
+    VO_LAUNCH_CHECK();
+    // the contenders, exactly (count_contenders_kernel above)
+    hipLaunchKernelGGL(count_contenders_kernel, dim3(64, batch), dim3(256), 0, s, models, clist, ncl, Hs, (const float4*)pts, n_dev, N,
+                       thr2, fund_bounds, counts);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
+}
+
 int vo_launch_mask_best(int kind, const double* models, int slots_per_problem, int slots_per_sample,
                         const double* aux, int aux_w, double* best_aux, const int32_t* result, const void* pts,
                         const float* img, const int32_t* n_dev, int N, int batch, const double* K4, float thr2,
@@ -1329,6 +1424,39 @@ extern "C" int vo_score_fund(const double* models, const uint8_t* valid, int H, 
     if (rc != VO_OK || N == 0) return rc;
     VO_CHECK_ARG(pts && ((uintptr_t)pts & 15) == 0, VO_EINVAL, "vo_score_fund: pts null or not 16-byte aligned");
     return vo_launch_score(kFund, models, valid, nullptr, nullptr, nullptr, H, pts, nullptr, nullptr, N, 1, nullptr, thr2, counts, H, s);
+}
+
+namespace {
+__global__ void outliers_to_bound_kernel(int32_t* counts, int H, int N)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < H) counts[i] = N - counts[i];
+}
+}  // namespace
+
+extern "C" int vo_score_fund_bound(const double* models, int H, const float* pts, int N, float thr2, int32_t* bound, void* stream)
+{
+    VO_CHECK_ARG(H >= 0 && N >= 0, VO_EINVAL, "vo_score_fund_bound: negative size");
+    if (H == 0) return VO_OK;
+    VO_CHECK_ARG(models && bound, VO_EINVAL, "vo_score_fund_bound: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    VO_HIP_TRY(hipMemsetAsync(bound, 0, (size_t)H * sizeof(int32_t), s));
+    if (N == 0) return VO_OK;
+    VO_CHECK_ARG(pts && ((uintptr_t)pts & 15) == 0, VO_EINVAL, "vo_score_fund_bound: pts null or not 16-byte aligned");
+    ScoreArgs a;
+    a.models = models; a.valid = nullptr; a.list = nullptr; a.nstart = nullptr; a.nlist = nullptr; a.pts = pts; a.img = nullptr;
+    a.n_dev = nullptr; a.counts = bound; a.H = H; a.N = N; a.thr2 = thr2; a.bounds = nullptr;
+    a.chunk = kMfChunk;
+    a.fx = a.fy = a.cx = a.cy = 0;
+    const int nchunks = vo_ceil_div(N, kMfChunk), xblocks = vo_ceil_div(H, kThreads);
+    long gy = (VO_SCORE_MF_TARGET + xblocks - 1) / xblocks;
+    if (gy > nchunks) gy = nchunks;
+    if (gy < 1) gy = 1;
+    hipLaunchKernelGGL(screen_fund_mfma_kernel, dim3(xblocks, (unsigned)gy, 1), dim3(kThreads), 0, s, a, (int)gy);
+    VO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(outliers_to_bound_kernel, dim3(vo_ceil_div(H, 256)), dim3(256), 0, s, bound, H, N);
+    VO_LAUNCH_CHECK();
+    return VO_OK;
 }
 
 extern "C" int vo_score_ess(const double* models, const uint8_t* valid, int H, const double* pts, int N,

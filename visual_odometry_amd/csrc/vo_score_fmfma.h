@@ -619,3 +619,196 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
     const int cnt = lds_load(&wcnt[w][lane]);
     if (live && cnt) atomicAdd(a.counts + gslot, cnt);
 }
+
+// ---- upper bounds instead of counts: the first tier alone ------------------------------------------------------------
+// The evaluations the matrix-core tier cannot prove to be outliers are a superset of the inliers, so
+//   ub(model) = correspondences - proven outliers  >=  the model's inlier count.
+// Inside a RANSAC run that is all most hypotheses need: a model whose upper bound does not exceed the best count of the
+// iterations already replayed can never be a strict improvement (OpenCV's loop only acts on good > maxGoodCount), so its
+// survivors need no second tier.  screen_fund_mfma_kernel is score_fund_mfma_kernel without queues and scalar tiers; the
+// tile is transposed back (correspondences along the rows, models along the columns: a lane's 16 accumulators are 16
+// correspondences of ONE model, so its proven outliers are a popcount of its own bit string).  It ADDS the proven
+// outliers of its chunks to counts[slot] (zero before); screen_finalize_kernel turns them into upper bounds and lists the
+// contenders, which score_fund_mfma_kernel then counts exactly (vo_launch_score_fund_pruned in vo_score.hip).
+// A problem with non-finite or huge coordinates proves nothing (every model a contender); so does a model outside the
+// tier's domain (mf_model_setup: s = 1, d = 0).
+__global__ __launch_bounds__(kThreads, VO_SCORE_MF_WAVES)
+void screen_fund_mfma_kernel(const ScoreArgs a, const int gy)
+{
+    constexpr int C = kMfChunk, kWaves = kThreads / 64;
+    static_assert(C >= kThreads, "the models' operands are staged through the feature planes");
+    __shared__ uint4 planebuf[4 * C];
+    uint4 (*planes)[C] = (uint4 (*)[C])planebuf;
+    uint4* const stagebuf = planebuf;
+    __shared__ uint32_t wc8[kWaves][64];
+    __shared__ uint32_t wslot[kWaves][64];                  // global slot of every model, ~0u past the end of the list
+    __shared__ double sscale[3][kWaves];
+
+    const int b = blockIdx.z;
+    const int n = a.n_dev ? min(a.n_dev[b], a.N) : a.N;
+    const int first = a.list && a.nstart ? a.nstart[b] : 0;
+    const int nslots = a.list ? a.nlist[b] - first : a.H;
+    const int nchunks = (n + C - 1) / C;
+    if ((int)blockIdx.y >= nchunks || (int)(blockIdx.x * kThreads) >= nslots) return;      // block-uniform
+    const float4* const pts = (const float4*)a.pts + (size_t)b * a.N;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, kh = lane >> 5, col = lane & 31;
+
+    const int t = blockIdx.x * kThreads + threadIdx.x;
+    int slot = t;
+    bool live = t < nslots;
+    if (a.list) slot = live ? a.list[(size_t)b * a.H + first + t] : 0;
+    const size_t gslot = (size_t)b * a.H + slot;
+    if (!a.list) live = live && (!a.valid || a.valid[gslot]);
+    double M[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) M[k] = live ? a.models[gslot * 9 + k] : 0.;
+    constexpr int kPer = (C + kThreads - 1) / kThreads;
+    const auto fetch = [&](int c, float4 (&v)[kPer]) {
+        const int p0 = c * C, np = min(C, n - p0);
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int i = threadIdx.x + u * kThreads;
+            v[u] = i < np ? pts[p0 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    float4 nxt[kPer];
+    fetch(blockIdx.y, nxt);
+
+    if (a.bounds) {
+        const float4 pb = *(const float4*)(a.bounds + 4 * (size_t)b);
+        if (lane == 0) { sscale[0][w] = (double)pb.x; sscale[1][w] = (double)pb.y; sscale[2][w] = (double)pb.z; }
+    } else {
+        float q1 = 1.f, q2 = 1.f;
+        bool tame = true;
+        for (int i = threadIdx.x; i < n; i += kThreads) {
+            const float4 v = pts[i];
+            q1 = fmaxf(q1, fmaxf(fabsf(v.x), fabsf(v.y)));
+            q2 = fmaxf(q2, fmaxf(fabsf(v.z), fabsf(v.w)));
+            tame = tame && fabsf(v.x) <= 0x1p20f && fabsf(v.y) <= 0x1p20f && fabsf(v.z) <= 0x1p20f && fabsf(v.w) <= 0x1p20f;
+        }
+        for (int o = 32; o; o >>= 1) {
+            q1 = fmaxf(q1, __shfl_xor(q1, o));
+            q2 = fmaxf(q2, __shfl_xor(q2, o));
+        }
+        tame = __all(tame);
+        if (lane == 0) { sscale[0][w] = (double)q1; sscale[1][w] = (double)q2; sscale[2][w] = tame ? 1. : 0.; }
+    }
+    __syncthreads();
+    double p1 = sscale[0][0], p2 = sscale[1][0], tame_all = sscale[2][0];
+#pragma unroll
+    for (int q = 1; q < kWaves; ++q) {
+        p1 = fmax(p1, sscale[0][q]);
+        p2 = fmax(p2, sscale[1][q]);
+        tame_all = fmin(tame_all, sscale[2][q]);
+    }
+    if (tame_all == 0.) return;                             // workgroup-uniform: nothing proven, every model stays a contender
+    int e1 = 0, e2 = 0;
+    (void)frexp(p1, &e1);
+    (void)frexp(p2, &e2);
+    const double P1 = ldexp(1., e1), P2 = ldexp(1., e2);
+    const float iP1 = (float)ldexp(1., -e1), iP2 = (float)ldexp(1., -e2);
+    {
+        MfModel mm;
+        mf_model_setup(M, live, a.thr2, p1, p2, P1, P2, mm);
+        uint4* st = &stagebuf[(size_t)threadIdx.x * 4];
+        st[0] = __builtin_bit_cast(uint4, mm.ch);
+        st[1] = __builtin_bit_cast(uint4, mm.cl);
+        st[2] = __builtin_bit_cast(uint4, mm.s0);
+        st[3] = __builtin_bit_cast(uint4, mm.s1);
+        wc8[w][lane] = __builtin_bit_cast(uint4, mm.c8).x;
+        wslot[w][lane] = live ? (uint32_t)gslot : ~0u;
+    }
+    __syncthreads();
+    v8h Md0[2], Md1[2], Ms[2];                               // the models' vectors: the MFMA's column-side operand
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int m = 64 * w + 32 * cb + col;
+        const uint4* st = &stagebuf[(size_t)m * 4];
+        Md0[cb] = __builtin_bit_cast(v8h, st[0]);
+        Md1[cb] = __builtin_bit_cast(v8h, kh ? make_uint4(wc8[w][32 * cb + col], 0u, 0u, 0u) : st[1]);
+        Ms[cb] = __builtin_bit_cast(v8h, st[2 + kh]);
+    }
+    uint32_t keep = kh ? 0u : ~0u, ones = kh ? 0x3c003c00u : 0u;
+    asm volatile("" : "+v"(keep), "+v"(ones));
+    const v16f zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint32_t outl[2] = {0u, 0u};                            // proven outliers of models 32 cb + col among this lane half's rows
+    for (int c = blockIdx.y; c < nchunks; c += gy) {
+        const int p0 = c * C, np = min(C, n - p0);
+        __syncthreads();                                     // the previous chunk (or the model staging) has been read
+        {
+            const int npad = (np + 63) & ~63;
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int i = threadIdx.x + u * kThreads;
+                if (i < npad) mf_stage_point(nxt[u], i < np, iP1, iP2, planes[0][i], planes[1][i], planes[2][i], planes[3][i]);
+            }
+        }
+        __syncthreads();
+        if (c + gy < nchunks) fetch(c + gy, nxt);
+        const int ngroups = (np + 63) >> 6;
+        for (int g = 0; g < ngroups; ++g) {
+            const int i0 = 64 * g;
+            v8h pd[2], ps[2];                                // the correspondences' vectors: the row-side operand
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                pd[h] = __builtin_bit_cast(v8h, planes[kh][i0 + 32 * h + col]);
+                ps[h] = __builtin_bit_cast(v8h, planes[2 + kh][i0 + 32 * h + col]);
+            }
+            uint32_t bits[2] = {0u, 0u};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                   // tile q: correspondence block q >> 1, model block q & 1
+                const int h = q >> 1, cb = q & 1;
+                const uint4 pdw = __builtin_bit_cast(uint4, pd[h]);
+                const v8h p1v = __builtin_bit_cast(v8h, make_uint4((pdw.x & keep) | ones, pdw.y & keep, pdw.z & keep, pdw.w & keep));
+                v16f accd = __builtin_amdgcn_mfma_f32_32x32x16_f16(pd[h], Md0[cb], zero16, 0, 0, 0);
+                accd = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1v, Md1[cb], accd, 0, 0, 0);
+                const v16f accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(ps[h], Ms[cb], zero16, 0, 0, 0);
+                bits[cb] = mf_epilogue(accd, accs, bits[cb]);
+            }
+            // bit 31 - 16 h - r of bits[cb]: correspondence i0 + 32 h + 8 (r >> 2) + 4 kh + (r & 3).  A padding row has
+            // zero features but still meets the constant term c~_8: mask it out of the ragged last group.
+            if (i0 + 64 > np) {
+                uint32_t vmask = 0u;
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    const int h = k >> 4, r = k & 15;
+                    if (i0 + 32 * h + 8 * (r >> 2) + 4 * kh + (r & 3) < np) vmask |= 1u << (31 - k);
+                }
+                bits[0] &= vmask;
+                bits[1] &= vmask;
+            }
+            outl[0] += (uint32_t)__popc(bits[0]);
+            outl[1] += (uint32_t)__popc(bits[1]);
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const uint32_t tot = outl[cb] + (uint32_t)__shfl_xor((int)outl[cb], 32);
+        const uint32_t gs = wslot[w][32 * cb + col];
+        if (kh == 0 && gs != ~0u && tot) atomicAdd(a.counts + gs, (int)tot);
+    }
+}
+
+// counts[slot] holds the proven outliers of list entries [nstart, nlist) of every problem: turn them into upper bounds;
+// a model whose bound exceeds the best count so far (result[4 b + 2]) goes to the contender list with its count reset to 0
+__global__ __launch_bounds__(256)
+void screen_finalize_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ nstart, const int32_t* __restrict__ nlist,
+                            int Hs, const int32_t* __restrict__ n_dev, int N, const int32_t* __restrict__ result,
+                            int32_t* __restrict__ counts, int32_t* __restrict__ clist, int32_t* __restrict__ ncl)
+{
+    const int b = blockIdx.y;
+    const int first = nstart ? nstart[b] : 0, cnt = nlist[b] - first;
+    const int n = n_dev ? min(n_dev[b], N) : N;
+    const int best = result[4 * b + 2];
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < cnt; t += gridDim.x * blockDim.x) {
+        const int slot = list[(size_t)b * Hs + first + t];
+        const size_t gs = (size_t)b * Hs + slot;
+        const int ub = n - counts[gs];
+        if (ub > best) {
+            clist[(size_t)b * Hs + atomicAdd(&ncl[b], 1)] = slot;
+            counts[gs] = 0;
+        } else {
+            counts[gs] = ub;
+        }
+    }
+}

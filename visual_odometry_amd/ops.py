@@ -135,6 +135,19 @@ def score_fund(models: torch.Tensor, pts4: torch.Tensor, threshold: float,
     return counts
 
 
+def score_fund_bound(models: torch.Tensor, pts4: torch.Tensor, threshold: float) -> torch.Tensor:
+    """Upper bounds of score_fund's counts from the F count kernel's first (matrix-core) tier alone: the correspondences it
+    cannot prove to be outliers (vo_score_fund_bound; what vo_ransac_batch prunes hopeless hypotheses with)."""
+    _lib.require_device()
+    models = _dev(models, torch.float64, "models").reshape(-1, 9)
+    pts4 = _dev(pts4, torch.float32, "pts4").reshape(-1, 4)
+    H, N = models.shape[0], pts4.shape[0]
+    bound = torch.empty((H,), dtype=torch.int32, device=models.device)
+    _lib.check(_lib.load().vo_score_fund_bound(_ptr(models), H, _ptr(pts4), N, thr2_of(threshold), _ptr(bound), _stream()),
+               "vo_score_fund_bound")
+    return bound
+
+
 def score_ess(models: torch.Tensor, pts4: torch.Tensor, threshold: float,
               valid: Optional[torch.Tensor] = None) -> torch.Tensor:
     _lib.require_device()
