@@ -488,10 +488,23 @@ def worker(args) -> int:
                       "lane-instructions/s peak.  Neither pipe is the limit any more: ~2.4 % of the evaluations are true inliers of their "
                       "hypothesis and take the complete two-sided f32 filter through a per-wave queue (LDS gathers, latency-bound), see "
                       "DESIGN.md 4.2; the scalar kernel this replaces needed 14.125 VALU instructions per evaluation and 1.7x the time")
+        pruned = F_FIRST_BLOCK > 0 and not shard
+        if pruned:
+            # blocks behind the first: every evaluation still goes through the matrix-core tier (screen_fund_mfma_kernel), the
+            # second tier runs only for the hypotheses that can still beat the best count (count_contenders_kernel)
+            c = kc("screen_fund_kernel")
+            sf["kernel"] = ("screen_fund_mfma_kernel (+ score_fund_mfma_kernel for the first block, screen_finalize_kernel, "
+                            "count_contenders_kernel: the launches of one pair batch's F scoring summed)")
+            both = [kc(k).get("hbm_bytes_per_launch") for k in ("screen_fund_kernel", "score_fund_kernel", "count_contenders_kernel")]
+            sf["traffic"] = sum(both) if all(v is not None for v in both) else None
+            sf["note"] += (f".  PRUNED BLOCKS (this run): the first {F_FIRST_BLOCK} iterations are counted as described; behind them the first "
+                           "tier alone gives every hypothesis an upper bound of its count, and only the ones whose bound beats the best count "
+                           "so far are counted exactly -- OpenCV's loop acts on good > maxGoodCount only, so F, mask and the iteration record "
+                           "are unchanged (tests); VO_BENCH_F_FIRST_BLOCK=0 times the unpruned form")
         if c.get("clock_ghz"):
             sf["clock_ghz_under_load"] = c["clock_ghz"]
             sf["frac_at_measured_clock"] = sf["achieved"] / (cus * F16_FLOP_PER_CLK_CU * c["clock_ghz"] * 1e9 / 1e12)
-        if c.get("SQ_INSTS_VALU") and c.get("evaluations_per_launch"):
+        if not pruned and c.get("SQ_INSTS_VALU") and c.get("evaluations_per_launch"):
             sf["valu_per_evaluation_from_SQ_INSTS_VALU"] = c["SQ_INSTS_VALU"] * 64 / c["evaluations_per_launch"]
     sp = valu_roofline("pnp", "PnP", evals_p, n_models_p, t_p, 20, 96, "score_pnp_kernel")
     sp["note"] = (sp.get("note") or "") + ("; in weak mode the PnP chain runs on a side stream under the two-view chain, so these launches "
@@ -513,8 +526,10 @@ def worker(args) -> int:
         roof["knn2"]["frac_at_measured_clock"] = roof["knn2"]["achieved"] / (cus * I8_OPS_PER_CLK_CU * ck * 1e9 / 1e12)
     dominant = max(tot, key=tot.get)
     pairs_total = B * args.steps * (1 if shard else world)
+    f_note = (f"; behind the first {F_FIRST_BLOCK} of them a hypothesis whose upper bound cannot beat the best inlier count so far is not "
+              "counted exactly -- F, mask and iteration record identical") if F_FIRST_BLOCK > 0 and not shard else ""
     wl = {"cfg4": f"cfg4: {NQ}x{NT}x128 SIFT match + ratio test -> matched correspondences (on device) -> {HF}-iteration "
-                  f"7-point F-RANSAC (thr 0.1 px: every iteration runs) and P3P PnP-RANSAC with maxIters {HP} (+ EPnP refit of "
+                  f"7-point F-RANSAC (thr 0.1 px: every iteration runs{f_note}) and P3P PnP-RANSAC with maxIters {HP} (+ EPnP refit of "
                   "its inliers) over them, per frame pair; ~91 % of the PnP correspondences are inliers, so OpenCV's adaptive "
                   "loop -- which the pipeline reproduces -- ends after 3-12 iterations: the first block of 64 iterations is what gets scored",
           "cfg5": f"cfg5 (one GPU's share of the sweep): {NQ}x{NT}x128 SIFT match + ratio test -> matched correspondences -> "

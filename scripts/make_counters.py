@@ -10,7 +10,7 @@ import sys
 
 tag = sys.argv[1]
 bench_args = sys.argv[2] if len(sys.argv) > 2 else ""
-SHORT = (("knn2_partial", "knn2_partial_kernel"), ("score_kernel<0>", "score_fund_kernel"), ("score_fund_mfma_kernel", "score_fund_kernel"), ("score_kernel<1>", "score_ess_kernel"),
+SHORT = (("knn2_partial", "knn2_partial_kernel"), ("score_kernel<0>", "score_fund_kernel"), ("score_fund_mfma_kernel", "score_fund_kernel"), ("screen_fund_mfma", "screen_fund_kernel"), ("count_contenders", "count_contenders_kernel"), ("score_kernel<1>", "score_ess_kernel"),
          ("score_kernel<2>", "score_pnp_kernel"), ("solve_7pt", "solve_7pt_kernel"), ("solve_p3p", "solve_p3p_kernel"),
          ("desc_f32_to_i8", "desc_f32_to_i8_kernel"), ("gen_subsets", "gen_subsets_kernel"), ("epnp_batch", "epnp_batch_kernel"))
 

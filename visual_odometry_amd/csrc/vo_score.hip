@@ -1269,7 +1269,7 @@ int vo_launch_score(int kind, const double* models, const uint8_t* valid, const 
 namespace {
 // Exact counts of the contenders of a pruned stage: they are few (tens per problem) and they are the GOOD hypotheses, dense
 // in survivors -- the opposite of what score_fund_mfma_kernel's queues are built for -- so each is simply walked by a whole
-// workgroup, thread per correspondence: the complete f32 filter, fund_decide64 where it cannot tell.  Workgroup j of
+// workgroup, thread per correspondence: the complete f32 filter, the f64 filter and the definition where it cannot tell.  Workgroup j of
 // problem b takes contenders j, j + gridDim.x, ...
 __global__ __launch_bounds__(256)
 void count_contenders_kernel(const double* __restrict__ models, const int32_t* __restrict__ clist, const int32_t* __restrict__ ncl,
@@ -1282,8 +1282,6 @@ void count_contenders_kernel(const double* __restrict__ models, const int32_t* _
     const float4* const pts = pts_all + (size_t)b * N;
     const float4 pb = *(const float4*)(bounds + 4 * (size_t)b);
     const double p1 = (double)pb.x, p2 = (double)pb.y;
-    __shared__ int und[4 * 256];
-    __shared__ int nund;
     for (int c = blockIdx.x; c < nc; c += gridDim.x) {
         const size_t gs = (size_t)b * Hs + clist[(size_t)b * Hs + c];
         const double* const model = models + gs * 9;
@@ -1291,6 +1289,9 @@ void count_contenders_kernel(const double* __restrict__ models, const int32_t* _
 #pragma unroll
         for (int k = 0; k < 9; ++k) M[k] = model[k];
         const FundFilter32 f32 = fund_filter32_setup(M, thr2, p1, p2);
+        // fund_decide64's tiers with the f64 filter constants set up once per contender instead of once per call: a good
+        // model has many residuals next to the threshold, some lane of every wave needs them in nearly every trip
+        const FundFilter g64 = fund_filter_setup(M, (double)thr2, p1, p2);
         int cnt = 0;
         for (int i0 = 0; i0 < n; i0 += 4 * 256) {           // four loads in flight per thread
             float4 v[4];
@@ -1299,24 +1300,15 @@ void count_contenders_kernel(const double* __restrict__ models, const int32_t* _
                 const int i = i0 + u * 256 + threadIdx.x;
                 v[u] = i < n ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (threadIdx.x == 0) nund = 0;
-            __syncthreads();
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 256 + threadIdx.x;
-                const int verdict = i < n ? fund_filter32(f32, v[u].x, v[u].y, v[u].z, v[u].w) : -1;
+                int verdict = i0 + u * 256 + (int)threadIdx.x < n ? fund_filter32(f32, v[u].x, v[u].y, v[u].z, v[u].w) : -1;
+                if (verdict == 0) {
+                    verdict = fund_filter(M, g64, v[u].x, v[u].y, v[u].z, v[u].w);
+                    if (verdict == 0) verdict = fund_err(M, v[u].x, v[u].y, v[u].z, v[u].w) <= thr2 ? 1 : -1;
+                }
                 cnt += verdict > 0;
-                if (verdict == 0) und[atomicAdd(&nund, 1)] = i;
             }
-            __syncthreads();
-            // what the f32 filter cannot tell (a good model has many residuals next to the threshold) is pooled over the
-            // workgroup, so that the f64 decisions run with full waves
-            const int nu = nund;
-            for (int t = threadIdx.x; t < nu; t += 256) {
-                const float4 w = pts[und[t]];
-                cnt += fund_decide64(model, w.x, w.y, w.z, w.w, thr2, p1, p2) ? 1 : 0;
-            }
-            __syncthreads();
         }
         for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
         if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(counts + gs, cnt);

@@ -632,10 +632,16 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
 // contenders, which score_fund_mfma_kernel then counts exactly (vo_launch_score_fund_pruned in vo_score.hip).
 // A problem with non-finite or huge coordinates proves nothing (every model a contender); so does a model outside the
 // tier's domain (mf_model_setup: s = 1, d = 0).
-__global__ __launch_bounds__(kThreads, VO_SCORE_MF_WAVES)
+#ifndef VO_SCREEN_CHUNK
+#define VO_SCREEN_CHUNK 256
+#endif
+#ifndef VO_SCREEN_WAVES
+#define VO_SCREEN_WAVES 4
+#endif
+__global__ __launch_bounds__(kThreads, VO_SCREEN_WAVES)
 void screen_fund_mfma_kernel(const ScoreArgs a, const int gy)
 {
-    constexpr int C = kMfChunk, kWaves = kThreads / 64;
+    constexpr int C = VO_SCREEN_CHUNK, kWaves = kThreads / 64;
     static_assert(C >= kThreads, "the models' operands are staged through the feature planes");
     __shared__ uint4 planebuf[4 * C];
     uint4 (*planes)[C] = (uint4 (*)[C])planebuf;
