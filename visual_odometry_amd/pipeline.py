@@ -183,7 +183,8 @@ def match_and_ransac(desc_q: torch.Tensor, desc_t: torch.Tensor, kp_q: torch.Ten
                      e_confidence: float = 0.9999, e_max_iters: Optional[int] = None, first_block_e: int = 0) -> PairBatchResult:
     """desc_* (B,n,128) f32 integer-valued, kp_* (B,n,2) f32, xyz_q (B,nq,3) f32 landmarks of the query
     keypoints (enables the PnP run when p_iters > 0).  first_block_*: see ops.ransac_batch (0 = evaluate all
-    iterations at once).  Everything is enqueued on the current stream, except the PnP chain (P3P RANSAC +
+    iterations at once; first_block_f = 256 is what bench.py and sweep.run_sweep use: hypotheses that cannot beat the
+    best count of the iterations before them get an upper bound instead of a count, same F / mask / record).  Everything is enqueued on the current stream, except the PnP chain (P3P RANSAC +
     EPnP refit), which runs on a side stream; with wait_pnp=True (default) the current
     stream waits for it before returning, with wait_pnp=False the caller does (`result.wait_pnp()`), which
     lets the small, latency-bound PnP kernels of one batch fill the gaps of the next batch's big ones.
