@@ -1267,33 +1267,56 @@ int vo_launch_score(int kind, const double* models, const uint8_t* valid, const 
 }
 
 namespace {
-// Exact counts of the contenders of a pruned stage: they are few (tens per problem) and they are the GOOD hypotheses, dense
-// in survivors -- the opposite of what score_fund_mfma_kernel's queues are built for -- so each is simply walked by a whole
-// workgroup, thread per correspondence: the complete f32 filter, the f64 filter and the definition where it cannot tell.  Workgroup j of
-// problem b takes contenders j, j + gridDim.x, ...
+// Exact counts of the contenders of a pruned stage: they are few (a few hundred per problem) and they are the GOOD
+// hypotheses, dense in survivors -- the opposite of what score_fund_mfma_kernel's queues are built for -- so each is simply
+// walked by a whole workgroup, thread per correspondence: the complete f32 filter, the f64 filter and the definition where
+// it cannot tell.  Workgroup j of problem b takes contenders j, j + gridDim.x, ...
+// The list is worked off in passes over growing iteration ranges [h_lo, h_hi): pass k leaves the best exact count it saw
+// in aux[4 b + 1 + k], and a contender of a LATER range whose bound does not beat the counts of the ranges before it is
+// dropped after all (every iteration of those ranges precedes it, so OpenCV's running best is at least that by then).
+// Counts of the SAME range must not be used: an earlier iteration of the range could be skipped because of a later one,
+// and an improvement that shortens niters would be lost.  counts[slot] holds the bound on entry (screen_finalize_kernel).
 __global__ __launch_bounds__(256)
-void count_contenders_kernel(const double* __restrict__ models, const int32_t* __restrict__ clist, const int32_t* __restrict__ ncl,
-                             int Hs, const float4* __restrict__ pts_all, const int32_t* __restrict__ n_dev, int N, float thr2,
+void count_contenders_kernel(const double* __restrict__ models, const int32_t* __restrict__ clist, int32_t* __restrict__ aux,
+                             int Hs, int width, int h_lo, int h_hi, int pass, const int32_t* __restrict__ result,
+                             const float4* __restrict__ pts_all, const int32_t* __restrict__ n_dev, int N, float thr2,
                              const float* __restrict__ bounds, int32_t* __restrict__ counts)
 {
-    const int b = blockIdx.y, nc = ncl[b];
+    __shared__ int wsum[4];
+    __shared__ FundFilter32 sf32;
+    __shared__ FundFilter sg64;
+    const int b = blockIdx.y, nc = aux[4 * b];
     if ((int)blockIdx.x >= nc) return;
     const int n = n_dev ? min(n_dev[b], N) : N;
     const float4* const pts = pts_all + (size_t)b * N;
     const float4 pb = *(const float4*)(bounds + 4 * (size_t)b);
     const double p1 = (double)pb.x, p2 = (double)pb.y;
-    for (int c = blockIdx.x; c < nc; c += gridDim.x) {
-        const size_t gs = (size_t)b * Hs + clist[(size_t)b * Hs + c];
+    int best = result[4 * b + 2];
+    for (int k = 0; k < pass; ++k) best = max(best, aux[4 * b + 1 + k]);
+    for (int c = blockIdx.x; c < nc; c += gridDim.x) {      // (everything that decides about c is workgroup-uniform)
+        const int slot = clist[(size_t)b * Hs + c], it = slot / width;
+        if (it < h_lo || it >= h_hi) continue;
+        const size_t gs = (size_t)b * Hs + slot;
+        if (counts[gs] <= best) continue;                    // the bound: a loser after all
         const double* const model = models + gs * 9;
         double M[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) M[k] = model[k];
-        const FundFilter32 f32 = fund_filter32_setup(M, thr2, p1, p2);
         // fund_decide64's tiers with the f64 filter constants set up once per contender instead of once per call: a good
-        // model has many residuals next to the threshold, some lane of every wave needs them in nearly every trip
-        const FundFilter g64 = fund_filter_setup(M, (double)thr2, p1, p2);
+        // model has many residuals next to the threshold, some lane of every wave needs them in nearly every trip.  The two
+        // set-ups are a few thousand f64 instructions: one wave does them for the workgroup (done by all four they were two
+        // thirds of this kernel's instructions)
+        __syncthreads();                                     // the previous contender's constants and sums have been read
+        if (threadIdx.x < 64) {
+            const FundFilter32 f = fund_filter32_setup(M, thr2, p1, p2);
+            const FundFilter g = fund_filter_setup(M, (double)thr2, p1, p2);
+            if (threadIdx.x == 0) { sf32 = f; sg64 = g; }
+        }
+        __syncthreads();
+        const FundFilter32 f32 = sf32;
+        const FundFilter g64 = sg64;
         int cnt = 0;
-        for (int i0 = 0; i0 < n; i0 += 4 * 256) {           // four loads in flight per thread
+        for (int i0 = 0; i0 < n; i0 += 4 * 256) {           // four loads in flight per thread (prefetching the next four: slower)
             float4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1311,7 +1334,13 @@ void count_contenders_kernel(const double* __restrict__ models, const int32_t* _
             }
         }
         for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
-        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(counts + gs, cnt);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            counts[gs] = total;
+            atomicMax(&aux[4 * b + 1 + pass], total);
+        }
     }
 }
 }  // namespace
@@ -1320,11 +1349,11 @@ void count_contenders_kernel(const double* __restrict__ models, const int32_t* _
 // b): the matrix-core tier alone gives every model of list entries [nstart, nlist) an upper bound of its count; only the
 // contenders -- bound above the best count -- are counted exactly.  counts[slot] ends as the exact count for contenders and
 // as an upper bound <= the best count for everybody else, which OpenCV's loop (good > maxGoodCount) cannot tell apart.
-// clist: batch x Hs ints, ncl: batch ints (scratch).
+// clist: batch x Hs ints, ncl: batch x 4 ints (scratch); width = model slots per iteration, [h_lo, h_hi) = the block's iterations.
 int vo_launch_score_fund_pruned(const double* models, const int32_t* list, const int32_t* nstart, const int32_t* nlist, int Hs,
                                 const void* pts, const int32_t* n_dev, int N, int batch, float thr2, int32_t* counts,
                                 int max_slots, const float* fund_bounds, const int32_t* result, int32_t* clist, int32_t* ncl,
-                                hipStream_t s)
+                                int width, int h_lo, int h_hi, hipStream_t s)
 {
     if (Hs == 0 || N == 0 || batch == 0) return VO_OK;
     VO_CHECK_ARG(batch <= 65535, VO_ESIZE, "score: batch=%d too large", batch);
@@ -1340,16 +1369,21 @@ int vo_launch_score_fund_pruned(const double* models, const int32_t* list, const
     long gy = (VO_SCORE_MF_TARGET + mblocks - 1) / mblocks;
     if (gy > nchunks) gy = nchunks;
     if (gy < 1) gy = 1;
-    VO_HIP_TRY(hipMemsetAsync(ncl, 0, (size_t)batch * sizeof(int32_t), s));
+    VO_HIP_TRY(hipMemsetAsync(ncl, 0, (size_t)batch * 4 * sizeof(int32_t), s));       // per problem: list length, best count of passes 0..2
     hipLaunchKernelGGL(screen_fund_mfma_kernel, dim3(xblocks, (unsigned)gy, batch), dim3(kThreads), 0, s, a, (int)gy);
     VO_LAUNCH_CHECK();
     hipLaunchKernelGGL(screen_finalize_kernel, dim3(xblocks < 64 ? xblocks : 64, batch), dim3(256), 0, s, list, nstart, nlist, Hs,
                        n_dev, N, result, counts, clist, ncl);
     VO_LAUNCH_CHECK();
-    // the contenders, exactly (count_contenders_kernel above)
-    hipLaunchKernelGGL(count_contenders_kernel, dim3(64, batch), dim3(256), 0, s, models, clist, ncl, Hs, (const float4*)pts, n_dev, N,
-                       thr2, fund_bounds, counts);
-    VO_LAUNCH_CHECK();
+    // the contenders, exactly, in three passes over growing iteration ranges (count_contenders_kernel above): 1/8, 3/8 and the
+    // rest of the block's iterations
+    const int hlen = h_hi - h_lo, cuts[4] = {h_lo, h_lo + (hlen + 7) / 8, h_lo + (hlen + 1) / 2, h_hi};
+    for (int pass = 0; pass < 3; ++pass) {
+        if (cuts[pass + 1] <= cuts[pass]) continue;
+        hipLaunchKernelGGL(count_contenders_kernel, dim3(64, batch), dim3(256), 0, s, models, clist, ncl, Hs, width, cuts[pass],
+                           cuts[pass + 1], pass, result, (const float4*)pts, n_dev, N, thr2, fund_bounds, counts);
+        VO_LAUNCH_CHECK();
+    }
     return VO_OK;
 }
 

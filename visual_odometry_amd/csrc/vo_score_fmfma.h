@@ -796,7 +796,7 @@ void screen_fund_mfma_kernel(const ScoreArgs a, const int gy)
 }
 
 // counts[slot] holds the proven outliers of list entries [nstart, nlist) of every problem: turn them into upper bounds;
-// a model whose bound exceeds the best count so far (result[4 b + 2]) goes to the contender list with its count reset to 0
+// a model whose bound exceeds the best count so far (result[4 b + 2]) goes to the contender list (length in ncl[4 b])
 __global__ __launch_bounds__(256)
 void screen_finalize_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ nstart, const int32_t* __restrict__ nlist,
                             int Hs, const int32_t* __restrict__ n_dev, int N, const int32_t* __restrict__ result,
@@ -810,11 +810,7 @@ void screen_finalize_kernel(const int32_t* __restrict__ list, const int32_t* __r
         const int slot = list[(size_t)b * Hs + first + t];
         const size_t gs = (size_t)b * Hs + slot;
         const int ub = n - counts[gs];
-        if (ub > best) {
-            clist[(size_t)b * Hs + atomicAdd(&ncl[b], 1)] = slot;
-            counts[gs] = 0;
-        } else {
-            counts[gs] = ub;
-        }
+        counts[gs] = ub;
+        if (ub > best) clist[(size_t)b * Hs + atomicAdd(&ncl[4 * b], 1)] = slot;
     }
 }
