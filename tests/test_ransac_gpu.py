@@ -183,7 +183,7 @@ def test_ransac_batch_fund_pruned_blocks_equal_one_block(dev, thr, first_block):
     """Blocks behind the first count only the hypotheses whose upper bound beats the best count so far (csrc/vo_score.hip:
     vo_launch_score_fund_pruned): result record, F and mask are those of the single exact block, bit for bit -- problems
     of different sizes in one batch (n_dev), one with every correspondence repeated four times (ties), one with fewer than
-    15 correspondences, a threshold so wide that every model is a contender."""
+    15 correspondences, one with non-finite coordinates, a threshold so wide that every model is a contender."""
     B, H, N = 6, 1500, 2400
     rng = np.random.default_rng(int(thr * 10) + first_block)
     pts = np.zeros((B, N, 4), np.float32); nd = np.zeros(B, np.int32); subs = np.zeros((B, H, 7), np.int32)
@@ -197,6 +197,7 @@ def test_ransac_batch_fund_pruned_blocks_equal_one_block(dev, thr, first_block):
         if n >= 15:
             subs[b] = ops.gen_subsets(n, 7, H, p)
     nd[4] = 0                                                   # (a problem without correspondences: no model)
+    pts[5, 7, 1] = np.inf; pts[5, 11, 2] = np.nan              # non-finite coordinates: nothing can be bounded, everybody is a contender
     outs = []
     for fb in (0, first_block):
         res, best, _, mask = ops.ransac_batch(ops.KIND_FUND, _d(subs, dev), _d(pts, dev), thr, 0.9999, H, n_dev=_d(nd, dev),
