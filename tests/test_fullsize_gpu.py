@@ -81,6 +81,22 @@ def test_fund_4096_hypotheses_8192_points(det_math, dev):
     assert np.array_equal(mask, omask) and np.array_equal(F, oF)
 
 
+@pytest.mark.parametrize("seed,outlier_frac,noise_px", [(91, 0.25, 0.5), (92, 0.6, 0.2), (93, 0.05, 1.0)])
+def test_fund_bench_size_pruned_blocks_against_the_oracle(det_math, dev, seed, outlier_frac, noise_px):
+    """The bench's F-RANSAC shape (~5000 correspondences, 4096 samples, 0.1 px) through vo_ransac_batch with first_block = 256
+    -- the first 256 iterations counted, the other 3840 bounded and only their contenders counted -- against the oracle's
+    sequential loop: iteration record, F and mask bit for bit."""
+    n = 4915
+    sc = synth.two_view_scene(n, seed=seed, outlier_frac=outlier_frac, noise_px=noise_px)
+    pts4 = np.concatenate([sc["p1"], sc["p2"]], 1).astype(np.float32)
+    subs = ops.gen_subsets(n, 7, 4096, pts4)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    res, best, _, mask = ops.ransac_batch(ops.KIND_FUND, d(subs[None]), d(pts4[None]), 0.1, 0.9999, 4096, first_block=256)
+    oF, omask, oinfo = det_math.find_fundamental_mat(pts4[:, :2], pts4[:, 2:], 0.1, 0.9999, 4096)
+    assert tuple(res[0].cpu().numpy()) == tuple(int(v) for v in oinfo)
+    assert np.array_equal(best[0].cpu().numpy().reshape(3, 3), oF) and np.array_equal(mask[0].cpu().numpy(), omask.ravel())
+
+
 def test_pair_pipeline_cfg5_size(det_math, dev):
     """cfg 5 through the fused batch: 32768 x 32768 descriptors per pair, 4096 F iterations and 65 536 PnP
     iterations (the oracle's sequential PnP loop stops early, the device replay must stop at the same
