@@ -193,7 +193,15 @@ __device__ __forceinline__ void jacobi_rows_reg(double (&A)[N1][M], double (&W)[
                 double a = W[0], p = 0, b = W[j];
 #pragma unroll
                 for (int k = 0; k < M; ++k) p += A[0][k] * A[j][k];
-                if (!(fabs(p) <= eps * sqrt(a * b))) {
+                // OpenCV's test is |p| <= eps sqrt(a b).  The square root only matters within rounding distance of equality:
+                // p^2 against eps^2 a b with a 2^-30 guard band decides everything else (both sides normal numbers, so neither
+                // product has lost bits to underflow; NaN and Inf fail both comparisons and take the exact test)
+                const double pp = p * p, rhs = (eps * eps) * (a * b);
+                bool rotate;
+                if (pp > rhs * (1. + 0x1p-30) && rhs >= minval) rotate = true;
+                else if (pp < rhs * (1. - 0x1p-30) && pp >= minval) rotate = false;
+                else rotate = !(fabs(p) <= eps * sqrt(a * b));
+                if (rotate) {
                     p *= 2;
                     const double beta = a - b, gamma = sqrt(p * p + beta * beta);
                     double c, s;
