@@ -1282,9 +1282,12 @@ void count_contenders_kernel(const double* __restrict__ models, const int32_t* _
                              const float4* __restrict__ pts_all, const int32_t* __restrict__ n_dev, int N, float thr2,
                              const float* __restrict__ bounds, int32_t* __restrict__ counts)
 {
+    constexpr int kUndCap = 1024;
     __shared__ int wsum[4];
     __shared__ FundFilter32 sf32;
     __shared__ FundFilter sg64;
+    __shared__ int und[kUndCap];
+    __shared__ int nund;
     const int b = blockIdx.y, nc = aux[4 * b];
     if ((int)blockIdx.x >= nc) return;
     const int n = n_dev ? min(n_dev[b], N) : N;
@@ -1310,7 +1313,7 @@ void count_contenders_kernel(const double* __restrict__ models, const int32_t* _
         if (threadIdx.x < 64) {
             const FundFilter32 f = fund_filter32_setup(M, thr2, p1, p2);
             const FundFilter g = fund_filter_setup(M, (double)thr2, p1, p2);
-            if (threadIdx.x == 0) { sf32 = f; sg64 = g; }
+            if (threadIdx.x == 0) { sf32 = f; sg64 = g; nund = 0; }
         }
         __syncthreads();
         const FundFilter32 f32 = sf32;
@@ -1325,13 +1328,29 @@ void count_contenders_kernel(const double* __restrict__ models, const int32_t* _
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                int verdict = i0 + u * 256 + (int)threadIdx.x < n ? fund_filter32(f32, v[u].x, v[u].y, v[u].z, v[u].w) : -1;
+                const int i = i0 + u * 256 + (int)threadIdx.x;
+                int verdict = i < n ? fund_filter32(f32, v[u].x, v[u].y, v[u].z, v[u].w) : -1;
                 if (verdict == 0) {
-                    verdict = fund_filter(M, g64, v[u].x, v[u].y, v[u].z, v[u].w);
-                    if (verdict == 0) verdict = fund_err(M, v[u].x, v[u].y, v[u].z, v[u].w) <= thr2 ? 1 : -1;
+                    // a good model has a residual next to the threshold in most trips of most waves, and one undecided lane
+                    // makes its whole wave walk the f64 tiers: pool them over the workgroup and decide them together below
+                    const int pos = atomicAdd(&nund, 1);
+                    if (pos < kUndCap) {
+                        und[pos] = i;
+                    } else {                                 // (list full: decide here)
+                        verdict = fund_filter(M, g64, v[u].x, v[u].y, v[u].z, v[u].w);
+                        if (verdict == 0) verdict = fund_err(M, v[u].x, v[u].y, v[u].z, v[u].w) <= thr2 ? 1 : -1;
+                    }
                 }
                 cnt += verdict > 0;
             }
+        }
+        __syncthreads();
+        const int nu = min(nund, kUndCap);
+        for (int t = threadIdx.x; t < nu; t += 256) {
+            const float4 w = pts[und[t]];
+            int verdict = fund_filter(M, g64, w.x, w.y, w.z, w.w);
+            if (verdict == 0) verdict = fund_err(M, w.x, w.y, w.z, w.w) <= thr2 ? 1 : -1;
+            cnt += verdict > 0;
         }
         for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
