@@ -41,11 +41,11 @@ int vo_launch_score(int kind, const double* models, const uint8_t* valid, const 
                     const double* K4, float thr2, int32_t* counts, int max_slots, hipStream_t s,
                     const float* fund_bounds = nullptr);
 // F scoring of list entries [nstart, nlist) behind a replayed block: upper bounds for everybody, exact counts for the
-// models whose bound exceeds result[4 b + 2] (vo_score.hip); clist batch x Hs ints, ncl batch x 4 ints of scratch; width = slots per iteration, [h_lo, h_hi) the block
+// models whose bound exceeds result[4 b + 2] (vo_score.hip); clist batch x Hs ints, ncl 17 batch + 1 ints of scratch
 int vo_launch_score_fund_pruned(const double* models, const int32_t* list, const int32_t* nstart, const int32_t* nlist, int Hs,
                                 const void* pts, const int32_t* n_dev, int N, int batch, float thr2, int32_t* counts,
                                 int max_slots, const float* fund_bounds, const int32_t* result, int32_t* clist, int32_t* ncl,
-                                int width, int h_lo, int h_hi, hipStream_t s);
+                                hipStream_t s);
 // per-problem bounds the F count kernel sets its models up with: (max |x1|,|y1|,1; max |x2|,|y2|,1; all coordinates tame ? 1 : 0; -)
 int vo_launch_fund_bounds(const void* pts, const int32_t* n_dev, int N, int batch, float* bounds, hipStream_t s);
 int vo_launch_mask_best(int kind, const double* models, int slots_per_problem, int slots_per_sample,

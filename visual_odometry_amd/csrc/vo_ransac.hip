@@ -223,7 +223,7 @@ RansacWs carve(void* base, int width, int mw, int aux_w, int H, int batch)
     w.clist = w.ncl = nullptr;
     if (width == 3) {                                    // F
         w.clist = (int32_t*)(p + off); off += align_up(slots * sizeof(int32_t));
-        w.ncl = (int32_t*)(p + off); off += align_up((size_t)batch * 4 * sizeof(int32_t));
+        w.ncl = (int32_t*)(p + off); off += align_up(((size_t)batch * 17 + 1) * sizeof(int32_t));
     }
     w.zero_from = off;
     w.nmodels = (int32_t*)(p + off); off += align_up((size_t)batch * H * sizeof(int32_t));
@@ -301,7 +301,7 @@ extern "C" int vo_ransac_batch(int kind, const int32_t* samples, int H, const vo
         // only a hypothesis that can beat it needs an exact count (vo_score.hip: upper bounds from the matrix-core tier)
         if (kind == VO_KIND_FUND && stage > 0)
             rc = vo_launch_score_fund_pruned(w.models, w.list, w.nstart, w.nlist, H * width, pts, n_dev, N, batch, thr2, w.counts,
-                                             hlen * width, w.bounds, result, w.clist, w.ncl, width, h0, h1, s);
+                                             hlen * width, w.bounds, result, w.clist, w.ncl, s);
         else
             rc = vo_launch_score(kind, w.models, nullptr, w.list, stage == 0 ? nullptr : w.nstart, w.nlist, H * width, pts, img,
                                  n_dev, N, batch, K4_host, thr2, w.counts, hlen * width, s, kind == VO_KIND_FUND ? w.bounds : nullptr);

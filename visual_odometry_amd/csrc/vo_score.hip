@@ -1267,20 +1267,38 @@ int vo_launch_score(int kind, const double* models, const uint8_t* valid, const 
 }
 
 namespace {
-// Exact counts of the contenders of a pruned stage: they are few (a few hundred per problem) and they are the GOOD
-// hypotheses, dense in survivors -- the opposite of what score_fund_mfma_kernel's queues are built for -- so each is simply
-// walked by a whole workgroup, thread per correspondence: the complete f32 filter, the f64 filter and the definition where
-// it cannot tell.  Workgroup j of problem b takes contenders j, j + gridDim.x, ...
-// The list is worked off in passes over growing iteration ranges [h_lo, h_hi): pass k leaves the best exact count it saw
-// in aux[4 b + 1 + k], and a contender of a LATER range whose bound does not beat the counts of the ranges before it is
-// dropped after all (every iteration of those ranges precedes it, so OpenCV's running best is at least that by then).
-// Counts of the SAME range must not be used: an earlier iteration of the range could be skipped because of a later one,
-// and an improvement that shortens niters would be lost.  counts[slot] holds the bound on entry (screen_finalize_kernel).
+// exclusive prefix sums of the per-problem contender counts (one counter per kNclStride ints): pre[b] = ncl[0] + ... + ncl[b-1],
+// pre[batch] = their number
+__global__ __launch_bounds__(1024)
+void contender_prefix_kernel(const int32_t* __restrict__ ncl, int batch, int32_t* __restrict__ pre)
+{
+    __shared__ int part[1024];
+    const int per = (batch + 1023) / 1024, lo = threadIdx.x * per, hi = min(batch, lo + per);
+    int sum = 0;
+    for (int b = lo; b < hi; ++b) sum += ncl[(size_t)b * kNclStride];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int add = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    for (int b = lo; b < hi; ++b) { pre[b] = run; run += ncl[(size_t)b * kNclStride]; }
+    if (threadIdx.x == 1023) pre[batch] = part[1023];
+}
+
+// Exact counts of the contenders of a pruned stage: they are few (a hundred or so per problem, very unevenly spread over
+// the problems) and they are the GOOD hypotheses, dense in survivors -- the opposite of what score_fund_mfma_kernel's queues
+// are built for -- so each is simply walked by a whole workgroup, thread per correspondence: the complete f32 filter, the
+// f64 filter and the definition where it cannot tell.  The contenders of all problems form one index space (prefix sums
+// of the per-problem list lengths): workgroup g takes contenders g, g + gridDim.x, ... of the whole batch, whichever
+// problem they belong to.  counts[slot] holds the bound on entry (screen_finalize_kernel) and the count on exit.
 __global__ __launch_bounds__(256)
-void count_contenders_kernel(const double* __restrict__ models, const int32_t* __restrict__ clist, int32_t* __restrict__ aux,
-                             int Hs, int width, int h_lo, int h_hi, int pass, const int32_t* __restrict__ result,
-                             const float4* __restrict__ pts_all, const int32_t* __restrict__ n_dev, int N, float thr2,
-                             const float* __restrict__ bounds, int32_t* __restrict__ counts)
+void count_contenders_kernel(const double* __restrict__ models, const int32_t* __restrict__ clist, const int32_t* __restrict__ pre,
+                             int batch, int Hs, const float4* __restrict__ pts_all, const int32_t* __restrict__ n_dev, int N,
+                             float thr2, const float* __restrict__ bounds, int32_t* __restrict__ counts)
 {
     constexpr int kUndCap = 1024;
     __shared__ int wsum[4];
@@ -1288,19 +1306,19 @@ void count_contenders_kernel(const double* __restrict__ models, const int32_t* _
     __shared__ FundFilter sg64;
     __shared__ int und[kUndCap];
     __shared__ int nund;
-    const int b = blockIdx.y, nc = aux[4 * b];
-    if ((int)blockIdx.x >= nc) return;
-    const int n = n_dev ? min(n_dev[b], N) : N;
-    const float4* const pts = pts_all + (size_t)b * N;
-    const float4 pb = *(const float4*)(bounds + 4 * (size_t)b);
-    const double p1 = (double)pb.x, p2 = (double)pb.y;
-    int best = result[4 * b + 2];
-    for (int k = 0; k < pass; ++k) best = max(best, aux[4 * b + 1 + k]);
-    for (int c = blockIdx.x; c < nc; c += gridDim.x) {      // (everything that decides about c is workgroup-uniform)
-        const int slot = clist[(size_t)b * Hs + c], it = slot / width;
-        if (it < h_lo || it >= h_hi) continue;
-        const size_t gs = (size_t)b * Hs + slot;
-        if (counts[gs] <= best) continue;                    // the bound: a loser after all
+    const int total = pre[batch];
+    for (int g = blockIdx.x; g < total; g += gridDim.x) {   // (everything that decides about g is workgroup-uniform)
+        int lo = 0, hi = batch;                              // the problem: the last b with pre[b] <= g
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] <= g) lo = mid; else hi = mid;
+        }
+        const int b = lo;
+        const int n = n_dev ? min(n_dev[b], N) : N;
+        const float4* const pts = pts_all + (size_t)b * N;
+        const float4 pb = *(const float4*)(bounds + 4 * (size_t)b);
+        const double p1 = (double)pb.x, p2 = (double)pb.y;
+        const size_t gs = (size_t)b * Hs + clist[(size_t)b * Hs + (g - pre[b])];
         const double* const model = models + gs * 9;
         double M[9];
 #pragma unroll
@@ -1355,11 +1373,7 @@ void count_contenders_kernel(const double* __restrict__ models, const int32_t* _
         for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-            counts[gs] = total;
-            atomicMax(&aux[4 * b + 1 + pass], total);
-        }
+        if (threadIdx.x == 0) counts[gs] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
 }
 }  // namespace
@@ -1368,11 +1382,11 @@ void count_contenders_kernel(const double* __restrict__ models, const int32_t* _
 // b): the matrix-core tier alone gives every model of list entries [nstart, nlist) an upper bound of its count; only the
 // contenders -- bound above the best count -- are counted exactly.  counts[slot] ends as the exact count for contenders and
 // as an upper bound <= the best count for everybody else, which OpenCV's loop (good > maxGoodCount) cannot tell apart.
-// clist: batch x Hs ints, ncl: batch x 4 ints (scratch); width = model slots per iteration, [h_lo, h_hi) = the block's iterations.
+// clist: batch x Hs ints, ncl: 17 batch + 1 ints (scratch: list lengths, one per 16 ints, then their prefix sums).
 int vo_launch_score_fund_pruned(const double* models, const int32_t* list, const int32_t* nstart, const int32_t* nlist, int Hs,
                                 const void* pts, const int32_t* n_dev, int N, int batch, float thr2, int32_t* counts,
                                 int max_slots, const float* fund_bounds, const int32_t* result, int32_t* clist, int32_t* ncl,
-                                int width, int h_lo, int h_hi, hipStream_t s)
+                                hipStream_t s)
 {
     if (Hs == 0 || N == 0 || batch == 0) return VO_OK;
     VO_CHECK_ARG(batch <= 65535, VO_ESIZE, "score: batch=%d too large", batch);
@@ -1388,21 +1402,18 @@ int vo_launch_score_fund_pruned(const double* models, const int32_t* list, const
     long gy = (VO_SCORE_MF_TARGET + mblocks - 1) / mblocks;
     if (gy > nchunks) gy = nchunks;
     if (gy < 1) gy = 1;
-    VO_HIP_TRY(hipMemsetAsync(ncl, 0, (size_t)batch * 4 * sizeof(int32_t), s));       // per problem: list length, best count of passes 0..2
+    VO_HIP_TRY(hipMemsetAsync(ncl, 0, (size_t)batch * kNclStride * sizeof(int32_t), s));
     hipLaunchKernelGGL(screen_fund_mfma_kernel, dim3(xblocks, (unsigned)gy, batch), dim3(kThreads), 0, s, a, (int)gy);
     VO_LAUNCH_CHECK();
     hipLaunchKernelGGL(screen_finalize_kernel, dim3(xblocks < 64 ? xblocks : 64, batch), dim3(256), 0, s, list, nstart, nlist, Hs,
                        n_dev, N, result, counts, clist, ncl);
     VO_LAUNCH_CHECK();
-    // the contenders, exactly, in three passes over growing iteration ranges (count_contenders_kernel above): 1/8, 3/8 and the
-    // rest of the block's iterations
-    const int hlen = h_hi - h_lo, cuts[4] = {h_lo, h_lo + (hlen + 7) / 8, h_lo + (hlen + 1) / 2, h_hi};
-    for (int pass = 0; pass < 3; ++pass) {
-        if (cuts[pass + 1] <= cuts[pass]) continue;
-        hipLaunchKernelGGL(count_contenders_kernel, dim3(64, batch), dim3(256), 0, s, models, clist, ncl, Hs, width, cuts[pass],
-                           cuts[pass + 1], pass, result, (const float4*)pts, n_dev, N, thr2, fund_bounds, counts);
-        VO_LAUNCH_CHECK();
-    }
+    // the contenders, exactly (count_contenders_kernel above), as one index space over the batch
+    hipLaunchKernelGGL(contender_prefix_kernel, dim3(1), dim3(1024), 0, s, ncl, batch, ncl + (size_t)batch * kNclStride);
+    VO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(count_contenders_kernel, dim3(8192), dim3(256), 0, s, models, clist, ncl + (size_t)batch * kNclStride, batch, Hs, (const float4*)pts,
+                       n_dev, N, thr2, fund_bounds, counts);
+    VO_LAUNCH_CHECK();
     return VO_OK;
 }
 

