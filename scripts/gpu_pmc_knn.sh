@@ -16,7 +16,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"gpurun_out/{tag}_pmc_*/pmc_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        s = "knn2_partial_kernel" if "knn2_partial" in k else "score_kernel<F>" if "score_kernel<0>" in k else None
+        s = "knn2_partial_kernel" if "knn2_partial" in k else "score_kernel<F>" if "score_kernel<0>" in k else "screen_fund_mfma_kernel" if "screen_fund_mfma" in k else "count_contenders_kernel" if "count_contenders" in k else None
         if s:
             acc[s][r["Counter_Name"]].append(float(r["Counter_Value"]))
             if r["Counter_Name"] in ("GRBM_GUI_ACTIVE", "SQ_INSTS_LDS"):
