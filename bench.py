@@ -560,7 +560,7 @@ def worker(args) -> int:
                      "baseline runs -- the rest from the device generator of the same recipe); random-init, no dataset",
         "config": {"workload": wl, "pairs_per_step": B if shard else B * world, "pairs_per_gpu_per_step": None if shard else B,
                    "mode": args.mode, "two_view_chain": "essential (5-point, Sampson)" if ess else "fundamental (7-point, symmetric epipolar)",
-                   "pose_tail_in_step": not args.no_pose_tail and not ess, "descriptor_prefetch": prefetch, "parallelism": par_note, "process_group": f"nccl (RCCL), world size {world}"},
+                   "pose_tail_in_step": not args.no_pose_tail and not ess, "f_first_block": (F_FIRST_BLOCK if not shard and not ess else 0), "descriptor_prefetch": prefetch, "parallelism": par_note, "process_group": f"nccl (RCCL), world size {world}"},
         "ransac_scoring": {"metric": "RANSAC hypotheses x points scored/sec",
                            "value": evals_f / t_f,
                            "unit": f"evaluations/s per GPU inside the {'E' if ess else 'F'} scoring kernel (models that exist x correspondences)",
