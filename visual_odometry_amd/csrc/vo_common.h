@@ -70,7 +70,7 @@ int vo_launch_solve_p3p(const int32_t* samples, int H, int per, const float* obj
                         int32_t* nlist, int h0, int hlen, const int32_t* prev, hipStream_t s);
 int vo_launch_replay(const int32_t* counts, const int32_t* nmodels, int n_iters, int max_models, int n_points,
                      const int32_t* n_dev, int model_points, double confidence, int max_iters, int batch,
-                     int32_t* result, hipStream_t s);
+                     int32_t* result, hipStream_t s, int scan_iters = 0);
 
 int vo_launch_gen_subsets(const int32_t* n_dev, int N, int model_points, int H, const float* pts4, int batch,
                           int32_t* samples, int32_t* n_generated, int max_attempts, hipStream_t s);

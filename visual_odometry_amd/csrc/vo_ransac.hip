@@ -42,15 +42,17 @@ template <int kReplayThreads>
 __global__ __launch_bounds__(kReplayThreads)
 void ransac_replay_kernel(const int32_t* __restrict__ counts, const int32_t* __restrict__ nmodels,
                           int n_iters, int max_models, int n_points, const int32_t* __restrict__ n_dev,
-                          int model_points, double confidence, int max_iters, int32_t* __restrict__ result)
+                          int model_points, double confidence, int max_iters, int32_t* __restrict__ result, int scan_iters)
 {
     constexpr int kReplayWaves = kReplayThreads / 64;
     __shared__ int s_wmax[kReplayWaves], s_wcnt[kReplayWaves];
     __shared__ int2 s_rec[kReplayThreads];
     __shared__ int s_niters, s_good, s_best_iter, s_best_k, s_stop;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
-    const long len = (long)n_iters * max_models;
-    counts += (size_t)b * len;
+    const long stride = (long)n_iters * max_models;
+    // only the first scan_iters iterations can hold models yet (a block-wise run replays after every block)
+    const long len = (long)(scan_iters < n_iters ? scan_iters : n_iters) * max_models;
+    counts += (size_t)b * stride;
     if (nmodels) nmodels += (size_t)b * n_iters;
     const int npts = n_dev ? n_dev[b] : n_points;
     if (tid == 0) {
@@ -185,17 +187,18 @@ bool collinear_last(const float* pts4, const int32_t* idx, int count, int off)
 
 int vo_launch_replay(const int32_t* counts, const int32_t* nmodels, int n_iters, int max_models, int n_points,
                      const int32_t* n_dev, int model_points, double confidence, int max_iters, int batch,
-                     int32_t* result, hipStream_t s)
+                     int32_t* result, hipStream_t s, int scan_iters)
 {
     if (batch == 0) return VO_OK;
+    if (scan_iters <= 0 || scan_iters > n_iters) scan_iters = n_iters;
     // measured in the pair pipeline (12 288-entry F tables beside the PnP side stream): 256 threads 9.31 ms per step,
     // 1024 threads 9.41 -- the big workgroups wait for a whole CU
     if ((long)n_iters * max_models > 65536)
         hipLaunchKernelGGL(ransac_replay_kernel<1024>, dim3(batch), dim3(1024), 0, s, counts, nmodels, n_iters,
-                           max_models, n_points, n_dev, model_points, confidence, max_iters, result);
+                           max_models, n_points, n_dev, model_points, confidence, max_iters, result, scan_iters);
     else
         hipLaunchKernelGGL(ransac_replay_kernel<256>, dim3(batch), dim3(256), 0, s, counts, nmodels, n_iters,
-                           max_models, n_points, n_dev, model_points, confidence, max_iters, result);
+                           max_models, n_points, n_dev, model_points, confidence, max_iters, result, scan_iters);
     VO_LAUNCH_CHECK();
     return VO_OK;
 }
@@ -308,7 +311,7 @@ extern "C" int vo_ransac_batch(int kind, const int32_t* samples, int H, const vo
         vo_prof_end(VO_STAGE_SCORE, s);
         if (rc != VO_OK) return rc;
         vo_prof_begin(VO_STAGE_REPLAY, kind | (stage << 8), s);
-        rc = vo_launch_replay(w.counts, w.nmodels, H, width, N, n_dev, kModelPoints[kind], confidence, max_iters, batch, result, s);
+        rc = vo_launch_replay(w.counts, w.nmodels, H, width, N, n_dev, kModelPoints[kind], confidence, max_iters, batch, result, s, h1);
         vo_prof_end(VO_STAGE_REPLAY, s);
         if (rc != VO_OK) return rc;
         h0 = h1;
