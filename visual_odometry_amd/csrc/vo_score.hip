@@ -1398,12 +1398,13 @@ int vo_launch_score_fund_pruned(const double* models, const int32_t* list, const
     a.chunk = kMfChunk;
     a.fx = a.fy = a.cx = a.cy = 0;
     const int nchunks = vo_ceil_div(N, kMfChunk), xblocks = vo_ceil_div(max_slots, kThreads);
-    const long mblocks = (long)xblocks * batch;
+    const int sblocks = vo_ceil_div(max_slots, kThreads * VO_SCREEN_MB);            // the screening kernel's workgroups hold VO_SCREEN_MB blocks
+    const long mblocks = (long)sblocks * batch;
     long gy = (VO_SCORE_MF_TARGET + mblocks - 1) / mblocks;
     if (gy > nchunks) gy = nchunks;
     if (gy < 1) gy = 1;
     VO_HIP_TRY(hipMemsetAsync(ncl, 0, (size_t)batch * kNclStride * sizeof(int32_t), s));
-    hipLaunchKernelGGL(screen_fund_mfma_kernel, dim3(xblocks, (unsigned)gy, batch), dim3(kThreads), 0, s, a, (int)gy);
+    hipLaunchKernelGGL(screen_fund_mfma_kernel, dim3(sblocks, (unsigned)gy, batch), dim3(kThreads), 0, s, a, (int)gy);
     VO_LAUNCH_CHECK();
     hipLaunchKernelGGL(screen_finalize_kernel, dim3(xblocks < 64 ? xblocks : 64, batch), dim3(256), 0, s, list, nstart, nlist, Hs,
                        n_dev, N, result, counts, clist, ncl);
@@ -1504,7 +1505,7 @@ extern "C" int vo_score_fund_bound(const double* models, int H, const float* pts
     a.n_dev = nullptr; a.counts = bound; a.H = H; a.N = N; a.thr2 = thr2; a.bounds = nullptr;
     a.chunk = kMfChunk;
     a.fx = a.fy = a.cx = a.cy = 0;
-    const int nchunks = vo_ceil_div(N, kMfChunk), xblocks = vo_ceil_div(H, kThreads);
+    const int nchunks = vo_ceil_div(N, kMfChunk), xblocks = vo_ceil_div(H, kThreads * VO_SCREEN_MB);
     long gy = (VO_SCORE_MF_TARGET + xblocks - 1) / xblocks;
     if (gy > nchunks) gy = nchunks;
     if (gy < 1) gy = 1;

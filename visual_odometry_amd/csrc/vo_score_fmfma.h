@@ -638,16 +638,19 @@ void score_fund_mfma_kernel(const ScoreArgs a, const int gy)
 #ifndef VO_SCREEN_WAVES
 #define VO_SCREEN_WAVES 4
 #endif
+#ifndef VO_SCREEN_MB
+#define VO_SCREEN_MB 2               // blocks of 256 models per workgroup: the staged correspondences serve both
+#endif
 __global__ __launch_bounds__(kThreads, VO_SCREEN_WAVES)
 void screen_fund_mfma_kernel(const ScoreArgs a, const int gy)
 {
-    constexpr int C = VO_SCREEN_CHUNK, kWaves = kThreads / 64;
+    constexpr int C = VO_SCREEN_CHUNK, kWaves = kThreads / 64, kMB = VO_SCREEN_MB;       // kMB blocks of 256 models per workgroup
     static_assert(C >= kThreads, "the models' operands are staged through the feature planes");
     __shared__ uint4 planebuf[4 * C];
     uint4 (*planes)[C] = (uint4 (*)[C])planebuf;
     uint4* const stagebuf = planebuf;
     __shared__ uint32_t wc8[kWaves][64];
-    __shared__ uint32_t wslot[kWaves][64];                  // global slot of every model, ~0u past the end of the list
+    __shared__ uint32_t wslot[kMB][kWaves][64];             // global slot of every model, ~0u past the end of the list
     __shared__ double sscale[3][kWaves];
 
     const int b = blockIdx.z;
@@ -655,19 +658,25 @@ void screen_fund_mfma_kernel(const ScoreArgs a, const int gy)
     const int first = a.list && a.nstart ? a.nstart[b] : 0;
     const int nslots = a.list ? a.nlist[b] - first : a.H;
     const int nchunks = (n + C - 1) / C;
-    if ((int)blockIdx.y >= nchunks || (int)(blockIdx.x * kThreads) >= nslots) return;      // block-uniform
+    if ((int)blockIdx.y >= nchunks || (int)(blockIdx.x * kThreads * kMB) >= nslots) return;      // block-uniform
     const float4* const pts = (const float4*)a.pts + (size_t)b * a.N;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, kh = lane >> 5, col = lane & 31;
 
-    const int t = blockIdx.x * kThreads + threadIdx.x;
-    int slot = t;
-    bool live = t < nslots;
-    if (a.list) slot = live ? a.list[(size_t)b * a.H + first + t] : 0;
-    const size_t gslot = (size_t)b * a.H + slot;
-    if (!a.list) live = live && (!a.valid || a.valid[gslot]);
-    double M[9];
+    // this thread's kMB models (one per block of 256): the loads go out first
+    size_t gslot[kMB];
+    bool live[kMB];
+    double M[kMB][9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) M[k] = live ? a.models[gslot * 9 + k] : 0.;
+    for (int mb = 0; mb < kMB; ++mb) {
+        const int t = (blockIdx.x * kMB + mb) * kThreads + threadIdx.x;
+        int slot = t;
+        live[mb] = t < nslots;
+        if (a.list) slot = live[mb] ? a.list[(size_t)b * a.H + first + t] : 0;
+        gslot[mb] = (size_t)b * a.H + slot;
+        if (!a.list) live[mb] = live[mb] && (!a.valid || a.valid[gslot[mb]]);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) M[mb][k] = live[mb] ? a.models[gslot[mb] * 9 + k] : 0.;
+    }
     constexpr int kPer = (C + kThreads - 1) / kThreads;
     const auto fetch = [&](int c, float4 (&v)[kPer]) {
         const int p0 = c * C, np = min(C, n - p0);
@@ -713,31 +722,37 @@ void screen_fund_mfma_kernel(const ScoreArgs a, const int gy)
     (void)frexp(p2, &e2);
     const double P1 = ldexp(1., e1), P2 = ldexp(1., e2);
     const float iP1 = (float)ldexp(1., -e1), iP2 = (float)ldexp(1., -e2);
-    {
-        MfModel mm;
-        mf_model_setup(M, live, a.thr2, p1, p2, P1, P2, mm);
-        uint4* st = &stagebuf[(size_t)threadIdx.x * 4];
-        st[0] = __builtin_bit_cast(uint4, mm.ch);
-        st[1] = __builtin_bit_cast(uint4, mm.cl);
-        st[2] = __builtin_bit_cast(uint4, mm.s0);
-        st[3] = __builtin_bit_cast(uint4, mm.s1);
-        wc8[w][lane] = __builtin_bit_cast(uint4, mm.c8).x;
-        wslot[w][lane] = live ? (uint32_t)gslot : ~0u;
-    }
-    __syncthreads();
-    v8h Md0[2], Md1[2], Ms[2];                               // the models' vectors: the MFMA's column-side operand
+    v8h Md0[kMB][2], Md1[kMB][2], Ms[kMB][2];                // the models' vectors: the MFMA's column-side operand
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int m = 64 * w + 32 * cb + col;
-        const uint4* st = &stagebuf[(size_t)m * 4];
-        Md0[cb] = __builtin_bit_cast(v8h, st[0]);
-        Md1[cb] = __builtin_bit_cast(v8h, kh ? make_uint4(wc8[w][32 * cb + col], 0u, 0u, 0u) : st[1]);
-        Ms[cb] = __builtin_bit_cast(v8h, st[2 + kh]);
+    for (int mb = 0; mb < kMB; ++mb) {
+        if (mb) __syncthreads();                             // the staging buffer has been read
+        {
+            MfModel mm;
+            mf_model_setup(M[mb], live[mb], a.thr2, p1, p2, P1, P2, mm);
+            uint4* st = &stagebuf[(size_t)threadIdx.x * 4];
+            st[0] = __builtin_bit_cast(uint4, mm.ch);
+            st[1] = __builtin_bit_cast(uint4, mm.cl);
+            st[2] = __builtin_bit_cast(uint4, mm.s0);
+            st[3] = __builtin_bit_cast(uint4, mm.s1);
+            wc8[w][lane] = __builtin_bit_cast(uint4, mm.c8).x;
+            wslot[mb][w][lane] = live[mb] ? (uint32_t)gslot[mb] : ~0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int m = 64 * w + 32 * cb + col;
+            const uint4* st = &stagebuf[(size_t)m * 4];
+            Md0[mb][cb] = __builtin_bit_cast(v8h, st[0]);
+            Md1[mb][cb] = __builtin_bit_cast(v8h, kh ? make_uint4(wc8[w][32 * cb + col], 0u, 0u, 0u) : st[1]);
+            Ms[mb][cb] = __builtin_bit_cast(v8h, st[2 + kh]);
+        }
     }
     uint32_t keep = kh ? 0u : ~0u, ones = kh ? 0x3c003c00u : 0u;
     asm volatile("" : "+v"(keep), "+v"(ones));
     const v16f zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    uint32_t outl[2] = {0u, 0u};                            // proven outliers of models 32 cb + col among this lane half's rows
+    uint32_t outl[kMB][2];                                  // proven outliers of models 32 cb + col (block mb) among this lane half's rows
+#pragma unroll
+    for (int mb = 0; mb < kMB; ++mb) outl[mb][0] = outl[mb][1] = 0u;
     for (int c = blockIdx.y; c < nchunks; c += gy) {
         const int p0 = c * C, np = min(C, n - p0);
         __syncthreads();                                     // the previous chunk (or the model staging) has been read
@@ -760,39 +775,47 @@ void screen_fund_mfma_kernel(const ScoreArgs a, const int gy)
                 pd[h] = __builtin_bit_cast(v8h, planes[kh][i0 + 32 * h + col]);
                 ps[h] = __builtin_bit_cast(v8h, planes[2 + kh][i0 + 32 * h + col]);
             }
-            uint32_t bits[2] = {0u, 0u};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {                   // tile q: correspondence block q >> 1, model block q & 1
-                const int h = q >> 1, cb = q & 1;
-                const uint4 pdw = __builtin_bit_cast(uint4, pd[h]);
-                const v8h p1v = __builtin_bit_cast(v8h, make_uint4((pdw.x & keep) | ones, pdw.y & keep, pdw.z & keep, pdw.w & keep));
-                v16f accd = __builtin_amdgcn_mfma_f32_32x32x16_f16(pd[h], Md0[cb], zero16, 0, 0, 0);
-                accd = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1v, Md1[cb], accd, 0, 0, 0);
-                const v16f accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(ps[h], Ms[cb], zero16, 0, 0, 0);
-                bits[cb] = mf_epilogue(accd, accs, bits[cb]);
-            }
-            // bit 31 - 16 h - r of bits[cb]: correspondence i0 + 32 h + 8 (r >> 2) + 4 kh + (r & 3).  A padding row has
-            // zero features but still meets the constant term c~_8: mask it out of the ragged last group.
+            // bit 31 - 16 h - r of a string: correspondence i0 + 32 h + 8 (r >> 2) + 4 kh + (r & 3).  A padding row has zero
+            // features but still meets the constant term c~_8: it is masked out of the ragged last group.
+            uint32_t vmask = ~0u;
             if (i0 + 64 > np) {
-                uint32_t vmask = 0u;
+                vmask = 0u;
 #pragma unroll
                 for (int k = 0; k < 32; ++k) {
                     const int h = k >> 4, r = k & 15;
                     if (i0 + 32 * h + 8 * (r >> 2) + 4 * kh + (r & 3) < np) vmask |= 1u << (31 - k);
                 }
-                bits[0] &= vmask;
-                bits[1] &= vmask;
             }
-            outl[0] += (uint32_t)__popc(bits[0]);
-            outl[1] += (uint32_t)__popc(bits[1]);
+            v8h p1v[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint4 pdw = __builtin_bit_cast(uint4, pd[h]);
+                p1v[h] = __builtin_bit_cast(v8h, make_uint4((pdw.x & keep) | ones, pdw.y & keep, pdw.z & keep, pdw.w & keep));
+            }
+#pragma unroll
+            for (int mb = 0; mb < kMB; ++mb) {
+                uint32_t bits[2] = {0u, 0u};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {               // tile q: correspondence block q >> 1, model block q & 1
+                    const int h = q >> 1, cb = q & 1;
+                    v16f accd = __builtin_amdgcn_mfma_f32_32x32x16_f16(pd[h], Md0[mb][cb], zero16, 0, 0, 0);
+                    accd = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1v[h], Md1[mb][cb], accd, 0, 0, 0);
+                    const v16f accs = __builtin_amdgcn_mfma_f32_32x32x16_f16(ps[h], Ms[mb][cb], zero16, 0, 0, 0);
+                    bits[cb] = mf_epilogue(accd, accs, bits[cb]);
+                }
+                outl[mb][0] += (uint32_t)__popc(bits[0] & vmask);
+                outl[mb][1] += (uint32_t)__popc(bits[1] & vmask);
+            }
         }
     }
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const uint32_t tot = outl[cb] + (uint32_t)__shfl_xor((int)outl[cb], 32);
-        const uint32_t gs = wslot[w][32 * cb + col];
-        if (kh == 0 && gs != ~0u && tot) atomicAdd(a.counts + gs, (int)tot);
-    }
+    for (int mb = 0; mb < kMB; ++mb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const uint32_t tot = outl[mb][cb] + (uint32_t)__shfl_xor((int)outl[mb][cb], 32);
+            const uint32_t gs = wslot[mb][w][32 * cb + col];
+            if (kh == 0 && gs != ~0u && tot) atomicAdd(a.counts + gs, (int)tot);
+        }
 }
 
 // counts[slot] holds the proven outliers of list entries [nstart, nlist) of every problem: turn them into upper bounds;
