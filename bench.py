@@ -554,7 +554,7 @@ def worker(args) -> int:
         "metric": "matched frame-pairs/sec", "value": pairs_total / dt, "unit": "frame-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
-        "dtype": "i8 (matching) / f64 (RANSAC; scoring filtered in f32, verdicts identical)",
+        "dtype": "i8 (matching) / f64 (RANSAC; scoring filtered by f16 hi/lo-split MFMA and f32 tiers, verdicts identical)",
         "data": "synthetic",
         "data_note": "every frame pair of a step is a different synthetic scene (4 from the host generator -- the ones the CPU "
                      "baseline runs -- the rest from the device generator of the same recipe); random-init, no dataset",
